@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- tracked frames/sec of the MI355X-native direct-VO hot path (BASELINE.json metric).
+
+One "step" = every sequence of the batch ingests its next 640x480 frame (gray + sensor depth + sigma, already
+resident in HBM), builds the 4-level pyramid and tracks it against its previous frame with the reference's
+coarse-to-fine Gauss-Newton loop (odometrizeUsingDepth, include/system/system.hpp:77-93) -> one relative pose
+per sequence, left in HBM.  value = sequences x steps x ranks / wall time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Independent sequences shard one batch per GPU (weak scaling); the only collective is the RCCL all_gather of
+the pose arrays after the timed steps (BASELINE config 5), timed separately as gather_ms.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "direct-visual-odometry_amd"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+GN_BYTES_PER_PIXEL = 16     # obj_gray + ref_gray + ref_depth + ref_sigma
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="sequences tracked concurrently per GPU")
+    ap.add_argument("--frames", type=int, default=8, help="distinct frames per sequence kept in HBM (ping-pong order)")
+    ap.add_argument("--workload", default="syn640", choices=["syn640", "syn1080"])
+    ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
+    ap.add_argument("--sigma", type=float, default=0.1, help="sensor sigma (src/core/transform.cpp:75)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def ring_index(k, n):
+    """0,1,..,n-1,n-2,..,1,0,1,..: consecutive frames are always neighbours of the trajectory."""
+    period = 2 * (n - 1)
+    r = k % period
+    return r if r < n else period - r
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libdvo has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    import dvo_amd as dvo
+    from dvo_amd import synth
+
+    if a.workload == "syn640":
+        W, H, K, levels, culls = 640, 480, synth.K_640, 4, 1          # Frame(g,d,s,K,4,1), system.hpp:82
+    else:
+        W, H, K, levels, culls = 1920, 1080, synth.K_1080, 5, 0
+        if a.fixed_iters == 0:
+            a.fixed_iters = 10
+    B, F = a.batch, max(2, a.frames)
+
+    # ---- synthetic sequences rendered straight into HBM: [F][B][H][W] --------------------------------
+    t_gen = time.time()
+    gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty_like(gray)
+    for b in range(B):
+        poses = synth.trajectory(F, seed=42 + 1000 * rank + b)
+        for f in range(F):
+            g, d = synth.render(poses[f], K, W, H, device=dev)
+            gray[f, b] = g
+            depth[f, b] = d
+    sigma = torch.full_like(gray, a.sigma)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    stream = torch.cuda.current_stream().cuda_stream
+    cfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters,
+                             crop_enable=1 if a.workload == "syn640" else 0)
+    batch = dvo.Batch(B, K, W, H, levels, culls, cfg=cfg)
+    poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
+
+    def push(bt, k, out=None):
+        f = ring_index(k, F)
+        bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
+        if out is not None:
+            bt.copy_poses_device(out.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    push(batch, 0)                          # first frame: reference only
+    for k in range(a.warmup):
+        push(batch, 1 + k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        push(batch, 1 + a.warmup + k, poses_out[k])
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    gather_ms = 0.0
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # config 5: gather every rank's poses over RCCL/xGMI (tens of KB: latency bound)
+        allp = torch.empty((world,) + tuple(poses_out.shape), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.all_gather_into_tensor(allp, poses_out)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+    dt = float(tmax.item())
+    fps = B * a.steps * world / dt
+    log0 = batch.last_track_log(0)
+    finite = bool(torch.isfinite(poses_out).all().item())
+
+    out = {
+        "metric": "tracked frames/sec (640x480 semi-dense) at 1 GPU" if a.workload == "syn640" else "tracked frames/sec (1920x1080 dense)",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SYN-640 (stand-in for TUM fr1/desk: no dataset offline), 640x480, sensor depth, "
+                               "frame-to-frame tracking, 4-level pyramid (320x240 top), reference thresholds"
+                   if a.workload == "syn640" else "SYN-1080 dense alignment, 5-level pyramid, fixed iterations",
+                   "sequences_per_gpu": B, "frames_in_hbm_per_sequence": F, "sigma": a.sigma,
+                   "fixed_iterations": a.fixed_iters, "iterations_per_level_seq0": log0["n_iter"],
+                   "poses_finite": finite, "gather_ms": gather_ms, "datagen_s": round(t_gen, 2)},
+    }
+
+    # ---- roofline of the dominant kernel (k_track_gn): HIP events around every launch of an identical pass ----
+    if not a.no_roofline:
+        pcfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, profile=1,
+                                  crop_enable=1 if a.workload == "syn640" else 0)
+        pb = dvo.Batch(B, K, W, H, levels, culls, cfg=pcfg)
+        push(pb, 0)
+        for k in range(a.warmup):
+            push(pb, 1 + k)
+        pb.profile(reset=True)
+        for k in range(a.steps):
+            push(pb, 1 + a.warmup + k)
+        pr = pb.profile()
+        top_ms, top_px = pb.probe_gn(levels - 1, 20)
+        pb.close()
+        if pr["gn_launches"] > 0 and pr["gn_ms"] > 0:
+            bytes_per_launch = GN_BYTES_PER_PIXEL * pr["gn_pixels"] / pr["gn_launches"]
+            ms_per_launch = pr["gn_ms"] / pr["gn_launches"]
+            achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_track_gn",
+                               "avg_launch_us": ms_per_launch * 1e3, "launches": pr["gn_launches"],
+                               "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "gn_share_of_step_time": pr["gn_ms"] / (dt * 1e3),
+                               "top_level_probe": {"avg_launch_us": top_ms * 1e3,
+                                                   "achieved": GN_BYTES_PER_PIXEL * top_px / (top_ms * 1e-3) / 1e9}}
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----------
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        g0 = gray[:, 0].cpu().numpy(); d0 = depth[:, 0].cpu().numpy(); s0 = sigma[:, 0].cpu().numpy()
+
+        def run(variant, budget):
+            n, t_start = 0, time.perf_counter()
+            ref = orc.OFrame(g0[0], d0[0], s0[0], K, levels, culls)
+            k = 0
+            while time.perf_counter() - t_start < budget:
+                f = ring_index(1 + k, F)
+                obj = orc.OFrame(g0[f], d0[f], s0[f], K, levels, culls)
+                orc.track(obj, ref, crop=(a.workload == "syn640"), variant=variant, fixed_iters=a.fixed_iters)
+                ref = obj
+                n += 1; k += 1
+            return n / (time.perf_counter() - t_start), n
+
+        faithful_fps, nf = run(1, a.cpu_seconds)
+        hoisted_fps, nh = run(0, max(3.0, a.cpu_seconds / 3))
+        out["cpu_baseline"] = {"value": faithful_fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d frame pairs of sequence 0 (same frames, pyramid + track), oracle 'faithful' "
+                                         "variant: per-pixel se3 exp, materialised warpImage, Nx6 stack + SVD least squares" % nf,
+                               "hoisted_value": hoisted_fps, "hoisted_sample": "%d frame pairs, pose hoisted + 6x6 normal equations" % nh,
+                               "cpu": _cpu_model()}
+    batch.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip() + " (%d logical cores visible)" % os.cpu_count()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,596 @@
+// dvo_capi.cpp -- the extern "C" surface declared in include/dvo.h.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "dvo_engine.h"
+
+using namespace dvo;
+
+struct dvo_vo { VisualOdometry impl; };
+struct dvo_batch { Batch impl; };
+
+extern "C" {
+
+void dvo_config_default(dvo_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->max_iterations = 15;              // tracker.cpp:19
+    c->min_update = 5e-4f;               // tracker.cpp:17
+    c->min_residual = 5e-3f;             // tracker.cpp:16
+    c->fixed_iterations = 0;
+    c->crop_enable = 1;
+    c->step_default = 2.0f;              // optimize.cpp:22-26
+    c->step_level1 = 1.5f;
+    c->step_level2 = 1.0f;
+    c->sigma_min = 0.01f;                // optimize.cpp:83
+    c->sigma_max = 0.5f;
+    c->min_depth = 0.20f;                // optimize.cpp:39
+    c->keyframe_min_translation = 0.02f; // mapper.cpp:12
+    c->keyframe_max_frames = 6;          // mapper.cpp:13
+    c->rng_seed = 0;
+    c->device = 0;
+    c->stream = nullptr;
+    c->profile = 0;
+    c->gn_pixels_per_thread = 0;
+    c->gn_use_lds_patch = -1;
+}
+
+const char* dvo_version(void) { return "dvo-mi355x 0.1 (gfx950)"; }
+
+const char* dvo_status_string(int s)
+{
+    switch (s) {
+        case DVO_OK: return "ok";
+        case DVO_ERR_BAD_ARGUMENT: return "bad argument";
+        case DVO_ERR_HIP: return "HIP runtime error";
+        case DVO_ERR_NO_DEVICE: return "no HIP device (libdvo has no CPU fallback)";
+        case DVO_ERR_NO_VALID_PIXELS: return "no valid pixels";
+        case DVO_ERR_NOT_READY: return "not ready";
+        case DVO_ERR_OUT_OF_MEMORY: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char* dvo_last_error(void) { return last_error(); }
+
+int dvo_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ VisualOdometry
+int dvo_vo_create(const float K[9], int width, int height, const dvo_config* cfg, dvo_vo** out)
+{
+    if (!out) return DVO_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    dvo_vo* vo = new (std::nothrow) dvo_vo();
+    if (!vo) return DVO_ERR_OUT_OF_MEMORY;
+    const int st = vo->impl.init(K, width, height, cfg);
+    if (st != DVO_OK) { delete vo; return st; }
+    *out = vo;
+    return DVO_OK;
+}
+
+int dvo_vo_destroy(dvo_vo* vo)
+{
+    if (!vo) return DVO_OK;
+    (void)select_device(vo->impl.device);
+    if (vo->impl.stream) (void)hipStreamSynchronize(vo->impl.stream);
+    delete vo;
+    return DVO_OK;
+}
+
+int dvo_vo_set_initial_depth(dvo_vo* vo, const float* depth, const float* sigma)
+{
+    if (!vo || !depth || !sigma) return DVO_ERR_BAD_ARGUMENT;
+    const Geometry& g = vo->impl.geoM;
+    const size_t n = (size_t)g.w[g.top()] * g.h[g.top()];
+    vo->impl.init_depth.assign(depth, depth + n);
+    vo->impl.init_sigma.assign(sigma, sigma + n);
+    return DVO_OK;
+}
+
+int dvo_vo_init_keyframe(dvo_vo* vo, const float* gray, const float* depth, const float* sigma)
+{
+    if (!vo) return DVO_ERR_BAD_ARGUMENT;
+    return vo->impl.init_keyframe(gray, depth, sigma);
+}
+
+int dvo_vo_odometrize(dvo_vo* vo, const float* gray, float T_world[16], int* is_keyframe)
+{
+    if (!vo) return DVO_ERR_BAD_ARGUMENT;
+    return vo->impl.odometrize(gray, T_world, is_keyframe);
+}
+
+int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, const float* sigma, float T_rel[16])
+{
+    if (!vo) return DVO_ERR_BAD_ARGUMENT;
+    return vo->impl.odometrize_depth(gray, depth, sigma, T_rel);
+}
+
+int dvo_vo_keyframe_count(const dvo_vo* vo) { return vo ? (int)vo->impl.hist.size() : 0; }
+
+int dvo_vo_keyframe_info(const dvo_vo* vo, int index, int* id, int* levels, int* tw, int* th, float xi[6], float rel_xi[6])
+{
+    if (!vo || index < 0 || index >= (int)vo->impl.hist.size()) return DVO_ERR_BAD_ARGUMENT;  // frame.hpp:176 .at()
+    const Keyframe& k = *vo->impl.hist[index];
+    if (id) *id = k.id;
+    if (levels) *levels = k.fs.g.levels;
+    if (tw) *tw = k.fs.g.w[k.fs.g.top()];
+    if (th) *th = k.fs.g.h[k.fs.g.top()];
+    if (xi) memcpy(xi, k.xi, 6 * sizeof(float));
+    if (rel_xi) memcpy(rel_xi, k.rel_xi, 6 * sizeof(float));
+    return DVO_OK;
+}
+
+int dvo_vo_keyframe_get(const dvo_vo* vo, int index, int level, float* gray, float* depth, float* sigma, float* age, float K[9])
+{
+    if (!vo || index < 0 || index >= (int)vo->impl.hist.size()) return DVO_ERR_BAD_ARGUMENT;
+    const Keyframe& k = *vo->impl.hist[index];
+    if (level < 0 || level >= k.fs.g.levels) return DVO_ERR_BAD_ARGUMENT;  // frame.hpp:125 .at()
+    DVO_TRY(select_device(vo->impl.device));
+    hipStream_t s = vo->impl.stream;
+    const size_t n = (size_t)k.fs.g.w[level] * k.fs.g.h[level] * sizeof(float);
+    if (gray) DVO_HIP(hipMemcpyAsync(gray, k.fs.gray[level], n, hipMemcpyDeviceToHost, s));
+    if (depth) DVO_HIP(hipMemcpyAsync(depth, k.fs.depth[level], n, hipMemcpyDeviceToHost, s));
+    if (sigma) DVO_HIP(hipMemcpyAsync(sigma, k.fs.sigma[level], n, hipMemcpyDeviceToHost, s));
+    if (age) {
+        if (level != k.fs.g.top()) { set_error("age is stored for the top level only"); return DVO_ERR_BAD_ARGUMENT; }
+        DVO_HIP(hipMemcpyAsync(age, k.age.p, n, hipMemcpyDeviceToHost, s));
+    }
+    if (K) memcpy(K, k.fs.g.K9[level], 9 * sizeof(float));
+    DVO_HIP(hipStreamSynchronize(s));
+    return DVO_OK;
+}
+
+int dvo_vo_last_frame_pose(const dvo_vo* vo, int* id, float xi[6], float rel_xi[6])
+{
+    if (!vo) return DVO_ERR_BAD_ARGUMENT;
+    if (vo->impl.last_id < 0) return DVO_ERR_NOT_READY;
+    if (id) *id = vo->impl.last_id;
+    if (xi) memcpy(xi, vo->impl.last_xi, 6 * sizeof(float));
+    if (rel_xi) memcpy(rel_xi, vo->impl.last_rel, 6 * sizeof(float));
+    return DVO_OK;
+}
+
+int dvo_vo_last_valid_updates(const dvo_vo* vo) { return vo ? vo->impl.last_valid_updates : 0; }
+
+int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log)
+{
+    if (!vo || !log) return DVO_ERR_BAD_ARGUMENT;
+    *log = vo->impl.last_log;
+    return DVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+int dvo_batch_create(int n_seq, const float K[9], int width, int height, int levels, int culls, const dvo_config* cfg, dvo_batch** out)
+{
+    if (!out) return DVO_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    dvo_batch* b = new (std::nothrow) dvo_batch();
+    if (!b) return DVO_ERR_OUT_OF_MEMORY;
+    const int st = b->impl.init(n_seq, K, width, height, levels, culls, cfg);
+    if (st != DVO_OK) { delete b; return st; }
+    *out = b;
+    return DVO_OK;
+}
+
+int dvo_batch_destroy(dvo_batch* b)
+{
+    if (!b) return DVO_OK;
+    (void)select_device(b->impl.device);
+    if (b->impl.stream) (void)hipStreamSynchronize(b->impl.stream);
+    delete b;
+    return DVO_OK;
+}
+
+int dvo_batch_push_device(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    return b->impl.push_device(gray, depth, sigma);
+}
+
+int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
+{
+    if (!b || !gray || !depth || !sigma) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    DVO_TRY(select_device(B.device));
+    const size_t n = (size_t)B.n_seq * B.g.src_w * B.g.src_h * sizeof(float);
+    if (B.in_gray.bytes < n) { DVO_TRY(B.in_gray.alloc(n)); DVO_TRY(B.in_depth.alloc(n)); DVO_TRY(B.in_sigma.alloc(n)); }
+    DVO_HIP(hipMemcpyAsync(B.in_gray.p, gray, n, hipMemcpyHostToDevice, B.stream));
+    DVO_HIP(hipMemcpyAsync(B.in_depth.p, depth, n, hipMemcpyHostToDevice, B.stream));
+    DVO_HIP(hipMemcpyAsync(B.in_sigma.p, sigma, n, hipMemcpyHostToDevice, B.stream));
+    return B.push_device(B.in_gray.as<float>(), B.in_depth.as<float>(), B.in_sigma.as<float>());
+}
+
+int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    if (!B.have_poses) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(B.device));
+    if (xi_rel) DVO_HIP(hipMemcpyAsync(xi_rel, B.trk.xi_out.p, sizeof(float) * 6 * (size_t)B.n_seq, hipMemcpyDeviceToHost, B.stream));
+    if (T_rel) DVO_HIP(hipMemcpyAsync(T_rel, B.trk.T_out.p, sizeof(float) * 16 * (size_t)B.n_seq, hipMemcpyDeviceToHost, B.stream));
+    DVO_HIP(hipStreamSynchronize(B.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_copy_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    if (!B.have_poses) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(B.device));
+    if (xi_dst_dev) DVO_HIP(hipMemcpyAsync(xi_dst_dev, B.trk.xi_out.p, sizeof(float) * 6 * (size_t)B.n_seq, hipMemcpyDeviceToDevice, B.stream));
+    if (T_dst_dev) DVO_HIP(hipMemcpyAsync(T_dst_dev, B.trk.T_out.p, sizeof(float) * 16 * (size_t)B.n_seq, hipMemcpyDeviceToDevice, B.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_last_track_log(dvo_batch* b, int seq, dvo_track_log* log)
+{
+    if (!b || !log || seq < 0 || seq >= b->impl.n_seq) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    if (!B.have_poses) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(B.device));
+    DVO_HIP(hipMemcpyAsync(log, B.trk.log.as<dvo_track_log>() + seq, sizeof *log, hipMemcpyDeviceToHost, B.stream));
+    DVO_HIP(hipStreamSynchronize(B.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_synchronize(dvo_batch* b)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(b->impl.device));
+    DVO_HIP(hipStreamSynchronize(b->impl.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_profile(dvo_batch* b, dvo_gn_profile* out, int reset)
+{
+    if (!b || !out) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    DVO_TRY(select_device(B.device));
+    DVO_TRY(B.trk.collect_profile(B.stream));
+    unsigned long long c[2] = {0, 0};
+    DVO_HIP(hipMemcpy(c, B.trk.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    out->gn_ms = B.trk.prof_ms;
+    out->gn_launches = B.trk.prof_launches;
+    out->gn_pixels = c[0];
+    out->gn_iterations = c[1];
+    if (reset) {
+        B.trk.prof_ms = 0; B.trk.prof_launches = 0;
+        DVO_HIP(hipMemset(B.trk.counters.p, 0, sizeof c));
+    }
+    return DVO_OK;
+}
+
+int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, uint64_t* pixels_per_launch)
+{
+    if (!b || !avg_ms || n_launches < 1) return DVO_ERR_BAD_ARGUMENT;
+    Batch& B = b->impl;
+    if (level < 0 || level >= B.g.levels) return DVO_ERR_BAD_ARGUMENT;
+    if (B.cur < 0 || !B.have_poses) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(B.device));
+    // obj = the newest frame set, ref = the one before it: exactly the operands of the last track() call
+    const GnArgs ga = B.trk.gn_args(B.fs[B.cur], B.fs[B.cur ^ 1], level, nullptr, 1);
+    hipEvent_t e0, e1;
+    DVO_HIP(hipEventCreate(&e0));
+    DVO_HIP(hipEventCreate(&e1));
+    launch_track_gn(ga, B.n_seq, B.trk.ppt[level], B.stream);  // warm
+    DVO_HIP(hipEventRecord(e0, B.stream));
+    for (int i = 0; i < n_launches; i++) launch_track_gn(ga, B.n_seq, B.trk.ppt[level], B.stream);
+    DVO_HIP(hipEventRecord(e1, B.stream));
+    DVO_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    DVO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)n_launches;
+    if (pixels_per_launch) *pixels_per_launch = (uint64_t)B.n_seq * B.g.w[level] * B.g.h[level];
+    return DVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ operator level
+namespace {
+struct OpCtx {  // device selection + a private stream for one operator call
+    hipStream_t s = nullptr;
+    int open(int dev)
+    {
+        DVO_TRY(select_device(dev));
+        DVO_HIP(hipStreamCreate(&s));
+        return DVO_OK;
+    }
+    ~OpCtx() { if (s) (void)hipStreamDestroy(s); }
+};
+int upload(DevBuf& b, const float* host, size_t count, hipStream_t s)
+{
+    DVO_TRY(b.alloc(count * sizeof(float)));
+    DVO_HIP(hipMemcpyAsync(b.p, host, count * sizeof(float), hipMemcpyHostToDevice, s));
+    return DVO_OK;
+}
+int download(float* host, const void* dev, size_t count, hipStream_t s)
+{
+    DVO_HIP(hipMemcpyAsync(host, dev, count * sizeof(float), hipMemcpyDeviceToHost, s));
+    return DVO_OK;
+}
+Intr intr_of(const float K[9]) { return Intr{K[0], K[4], K[2], K[5]}; }
+}  // namespace
+
+int dvo_op_cull_image(int dev, const float* src, int w, int h, int times, float* dst)
+{
+    if (!src || !dst || w < 1 || h < 1 || times < 0 || times > 8) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h, dn = (size_t)(w >> times) * (h >> times);
+    if (dn == 0) return DVO_OK;  // empty output, as cv::Mat::zeros(0 x 0)
+    DevBuf a, b;
+    DVO_TRY(upload(a, src, n, c.s));
+    DVO_TRY(b.alloc(dn * 4));
+    launch_cull(a.as<float>(), w, h, times, b.as<float>(), c.s);
+    DVO_TRY(download(dst, b.p, dn, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_gradient(int dev, const float* img, int w, int h, int xdir, float* out)
+{
+    if (!img || !out || w < 1 || h < 1) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf a, b;
+    DVO_TRY(upload(a, img, n, c.s));
+    DVO_TRY(b.alloc(n * 4));
+    launch_gradient(a.as<float>(), w, h, xdir, b.as<float>(), c.s);
+    DVO_TRY(download(out, b.p, n, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_warp_image(int dev, const float xi[6], const float* gray, const float* depth, int w, int h, const float K[9], float* out)
+{
+    if (!xi || !gray || !depth || !K || !out || w < 1 || h < 1) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf g, d, o, xin, T;
+    DVO_TRY(upload(g, gray, n, c.s));
+    DVO_TRY(upload(d, depth, n, c.s));
+    DVO_TRY(o.alloc(n * 4));
+    // the pose comes from the DEVICE exp (that is what the tracker uses): exp(-xi)
+    float neg[6];
+    for (int i = 0; i < 6; i++) neg[i] = -xi[i];
+    DVO_TRY(upload(xin, neg, 6, c.s));
+    DVO_TRY(T.alloc(16 * 4));
+    launch_se3(0, xin.as<float>(), nullptr, T.as<float>(), c.s);
+    float Th[16];
+    DVO_TRY(download(Th, T.p, 16, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    Pose pose;
+    for (int r = 0; r < 3; r++) {
+        for (int q = 0; q < 3; q++) pose.R[3 * r + q] = Th[4 * r + q];
+        pose.t[r] = Th[4 * r + 3];
+    }
+    launch_warp_image(g.as<float>(), d.as<float>(), w, h, intr_of(K), pose, o.as<float>(), c.s);
+    DVO_TRY(download(out, o.p, n, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_pyramid(int dev, const float* gray, const float* depth, const float* sigma, int w, int h, int levels, int culls,
+                   float* const gray_out[], float* const depth_out[], float* const sigma_out[])
+{
+    if (!gray || !gray_out) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const float Kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Geometry g;
+    DVO_TRY(make_geometry(Kid, w, h, levels, culls, g));
+    FrameSet fs;
+    DVO_TRY(fs.alloc(g, 1));
+    const size_t n = (size_t)w * h;
+    DevBuf a, b, s3;
+    DVO_TRY(upload(a, gray, n, c.s));
+    if (depth) DVO_TRY(upload(b, depth, n, c.s));
+    if (sigma) DVO_TRY(upload(s3, sigma, n, c.s));
+    build_pyramid(fs, a.as<float>(), depth ? b.as<float>() : nullptr, sigma ? s3.as<float>() : nullptr, c.s);
+    for (int l = 0; l < levels; l++) {
+        const size_t ln = (size_t)g.w[l] * g.h[l];
+        if (gray_out[l]) DVO_TRY(download(gray_out[l], fs.gray[l], ln, c.s));
+        if (depth && depth_out && depth_out[l]) DVO_TRY(download(depth_out[l], fs.depth[l], ln, c.s));
+        if (sigma && sigma_out && sigma_out[l]) DVO_TRY(download(sigma_out[l], fs.sigma[l], ln, c.s));
+    }
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const float* ref_gray, const float* ref_depth,
+                   const float* ref_sigma, int w, int h, const float K[9], const float xi[6], int level,
+                   dvo_gn_result* out, uint8_t* mask)
+{
+    if (!obj_gray || !ref_gray || !ref_depth || !ref_sigma || !K || !xi || !out || w < 1 || h < 1 || level < 0 || level >= DVO_MAX_LEVELS)
+        return DVO_ERR_BAD_ARGUMENT;
+    dvo_config cf;
+    if (cfg) cf = *cfg; else dvo_config_default(&cf);
+    OpCtx c; DVO_TRY(c.open(dev));
+    // a one-level "pyramid" whose only level carries index `level` semantics (step size, crop)
+    Geometry g;
+    DVO_TRY(make_geometry(K, w, h, 1, 0, g));
+    // place the level at index `level` so Tracker::level_params / logs see the right index
+    Geometry gl = g;
+    gl.levels = level + 1;
+    for (int l = 0; l <= level; l++) { gl.w[l] = w; gl.h[l] = h; memcpy(gl.K9[l], g.K9[0], sizeof g.K9[0]); gl.k[l] = g.k[0]; }
+    Tracker trk;
+    DVO_TRY(trk.init(gl, 1, cf));
+    const size_t n = (size_t)w * h;
+    DevBuf og, rg, rd, rs, mk, xin, res;
+    DVO_TRY(upload(og, obj_gray, n, c.s));
+    DVO_TRY(upload(rg, ref_gray, n, c.s));
+    DVO_TRY(upload(rd, ref_depth, n, c.s));
+    DVO_TRY(upload(rs, ref_sigma, n, c.s));
+    DVO_TRY(upload(xin, xi, 6, c.s));
+    DVO_TRY(res.alloc(sizeof(dvo_gn_result)));
+    if (mask) { DVO_TRY(mk.alloc(n)); DVO_HIP(hipMemsetAsync(mk.p, 0, n, c.s)); }
+    launch_set_pose(trk.state.as<SeqState>(), xin.as<float>(), 1, c.s);
+    GnArgs ga;
+    ga.obj_gray = og.as<float>(); ga.ref_gray = rg.as<float>(); ga.ref_depth = rd.as<float>(); ga.ref_sigma = rs.as<float>();
+    ga.state = trk.state.as<SeqState>();
+    ga.partials = trk.partials.as<float>();
+    ga.mask = mask ? mk.as<uint8_t>() : nullptr;
+    ga.w = w; ga.h = h; ga.nblk = trk.nblk[level]; ga.inv_w = 1.0f / (float)w;
+    ga.k = gl.k[level];
+    ga.prm = trk.level_params(level);
+    ga.ignore_active = 1;
+    launch_track_gn(ga, 1, trk.ppt[level], c.s);
+    SolveArgs sa;
+    sa.state = trk.state.as<SeqState>(); sa.partials = trk.partials.as<float>();
+    sa.log = nullptr; sa.result = res.as<dvo_gn_result>(); sa.counters = nullptr;
+    sa.nblk = trk.nblk[level]; sa.level = level; sa.level_pixels = w * h;
+    sa.max_iterations = cf.max_iterations; sa.fixed_iterations = cf.fixed_iterations;
+    sa.min_update = cf.min_update; sa.min_residual = cf.min_residual; sa.ignore_active = 1;
+    launch_gn_solve(sa, 1, c.s);
+    DVO_HIP(hipMemcpyAsync(out, res.p, sizeof *out, hipMemcpyDeviceToHost, c.s));
+    if (mask) DVO_HIP(hipMemcpyAsync(mask, mk.p, n, hipMemcpyDeviceToHost, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int dvo_op_track(int dev, const dvo_config* cfg, const float* obj_gray, const float* ref_gray, const float* ref_depth,
+                 const float* ref_sigma, int w, int h, const float K[9], int levels, int culls, float xi_out[6], dvo_track_log* log)
+{
+    if (!obj_gray || !ref_gray || !ref_depth || !ref_sigma || !K || !xi_out) return DVO_ERR_BAD_ARGUMENT;
+    dvo_config cf;
+    if (cfg) cf = *cfg; else dvo_config_default(&cf);
+    OpCtx c; DVO_TRY(c.open(dev));
+    Geometry g;
+    DVO_TRY(make_geometry(K, w, h, levels, culls, g));
+    FrameSet obj, ref;
+    DVO_TRY(obj.alloc(g, 1));
+    DVO_TRY(ref.alloc(g, 1));
+    Tracker trk;
+    DVO_TRY(trk.init(g, 1, cf));
+    const size_t n = (size_t)w * h;
+    DevBuf og, rg, rd, rs;
+    DVO_TRY(upload(og, obj_gray, n, c.s));
+    DVO_TRY(upload(rg, ref_gray, n, c.s));
+    DVO_TRY(upload(rd, ref_depth, n, c.s));
+    DVO_TRY(upload(rs, ref_sigma, n, c.s));
+    build_pyramid(obj, og.as<float>(), nullptr, nullptr, c.s);
+    build_pyramid(ref, rg.as<float>(), rd.as<float>(), rs.as<float>(), c.s);
+    DVO_TRY(trk.track(obj, ref, c.s));
+    DVO_TRY(download(xi_out, trk.xi_out.p, 6, c.s));
+    if (log) DVO_HIP(hipMemcpyAsync(log, trk.log.p, sizeof *log, hipMemcpyDeviceToHost, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_propagate(int dev, const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h,
+                     const float xi[6], const float K[9], float* depth, float* sigma, float* age)
+{
+    if (!ref_depth || !ref_sigma || !ref_age || !xi || !K || !depth || !sigma || !age || w < 1 || h < 1) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf a, b, g, od, os, oa, ow;
+    DVO_TRY(upload(a, ref_depth, n, c.s));
+    DVO_TRY(upload(b, ref_sigma, n, c.s));
+    DVO_TRY(upload(g, ref_age, n, c.s));
+    DVO_TRY(od.alloc(n * 4)); DVO_TRY(os.alloc(n * 4)); DVO_TRY(oa.alloc(n * 4)); DVO_TRY(ow.alloc(n * 4));
+    Pose pose;
+    pose_from_xi(xi, 1.0f, pose);  // host double exp, as VisualOdometry::map_propagate does
+    launch_propagate(a.as<float>(), b.as<float>(), g.as<float>(), w, h, intr_of(K), pose, xi[2], ow.as<int>(),
+                     od.as<float>(), os.as<float>(), oa.as<float>(), c.s);
+    DVO_TRY(download(depth, od.p, n, c.s));
+    DVO_TRY(download(sigma, os.p, n, c.s));
+    DVO_TRY(download(age, oa.p, n, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_regularize(int dev, const float* depth, const float* sigma, int w, int h, float* out)
+{
+    if (!depth || !sigma || !out || w < 1 || h < 1) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf a, b, o;
+    DVO_TRY(upload(a, depth, n, c.s));
+    DVO_TRY(upload(b, sigma, n, c.s));
+    DVO_TRY(o.alloc(n * 4));
+    launch_regularize(a.as<float>(), b.as<float>(), w, h, o.as<float>(), c.s);
+    DVO_TRY(download(out, o.p, n, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float* const hist_gray[], const float* hist_xi,
+                        const float* obj_gray, const float obj_xi[6], const float obj_rel_xi[6], int obj_id,
+                        const float K[9], int w, int h, float* ref_depth, float* ref_sigma, float* ref_age, int* valid_updates)
+{
+    if (n_hist < 1 || !hist_gray || !hist_xi || !obj_gray || !obj_xi || !obj_rel_xi || !K || !ref_depth || !ref_sigma || !ref_age)
+        return DVO_ERR_BAD_ARGUMENT;
+    dvo_config cf;
+    if (cfg) cf = *cfg; else dvo_config_default(&cf);
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    std::vector<DevBuf> grays(n_hist);
+    std::vector<AgeEntry> tab(n_hist);
+    for (int i = 0; i < n_hist; i++) {
+        DVO_TRY(upload(grays[i], hist_gray[i], n, c.s));
+        float nb[6], r_xi[6];
+        for (int k = 0; k < 6; k++) nb[k] = -hist_xi[6 * i + k];
+        se3_concatenate_f(obj_xi, nb, r_xi);
+        pose_from_xi(r_xi, -1.0f, tab[i].pose);
+        for (int k = 0; k < 3; k++) tab[i].tneg[k] = -r_xi[k];
+        tab[i].gray = grays[i].as<float>();
+    }
+    DevBuf og, rd, rs, ra, ages, vd;
+    DVO_TRY(upload(og, obj_gray, n, c.s));
+    DVO_TRY(upload(rd, ref_depth, n, c.s));
+    DVO_TRY(upload(rs, ref_sigma, n, c.s));
+    DVO_TRY(upload(ra, ref_age, n, c.s));
+    DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist));
+    DVO_HIP(hipMemcpyAsync(ages.p, tab.data(), sizeof(AgeEntry) * (size_t)n_hist, hipMemcpyHostToDevice, c.s));
+    DVO_TRY(vd.alloc(sizeof(int)));
+    DVO_HIP(hipMemsetAsync(vd.p, 0, sizeof(int), c.s));
+    UpdateArgs a;
+    a.ref_depth = rd.as<float>(); a.ref_sigma = rs.as<float>(); a.ref_age = ra.as<float>();
+    a.obj_gray = og.as<float>(); a.ages = ages.as<AgeEntry>();
+    a.n_hist = n_hist; a.w = w; a.h = h; a.crop = cf.crop_enable; a.obj_id = obj_id; a.seed = cf.rng_seed;
+    a.k = intr_of(K);
+    memcpy(a.K9, K, sizeof a.K9);
+    pose_from_xi(obj_rel_xi, 1.0f, a.rel_pose);
+    a.rel_tz = obj_rel_xi[2];
+    a.valid_updates = vd.as<int>();
+    launch_depth_update(a, c.s);
+    DVO_TRY(download(ref_depth, rd.p, n, c.s));
+    DVO_TRY(download(ref_sigma, rs.p, n, c.s));
+    DVO_TRY(download(ref_age, ra.p, n, c.s));
+    int v = 0;
+    DVO_HIP(hipMemcpyAsync(&v, vd.p, sizeof v, hipMemcpyDeviceToHost, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    if (valid_updates) *valid_updates = v;
+    return DVO_OK;
+}
+
+static int se3_op(int dev, int op, const float* a, int na, const float* b, float* out, int nout)
+{
+    OpCtx c; DVO_TRY(c.open(dev));
+    DevBuf da, db, dout;
+    DVO_TRY(upload(da, a, na, c.s));
+    if (b) DVO_TRY(upload(db, b, 6, c.s));
+    DVO_TRY(dout.alloc(16 * 4));
+    launch_se3(op, da.as<float>(), b ? db.as<float>() : nullptr, dout.as<float>(), c.s);
+    DVO_TRY(download(out, dout.p, nout, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_se3_exp(int dev, const float xi[6], float T[16]) { return (xi && T) ? se3_op(dev, 0, xi, 6, nullptr, T, 16) : DVO_ERR_BAD_ARGUMENT; }
+int dvo_op_se3_log(int dev, const float T[16], float xi[6]) { return (xi && T) ? se3_op(dev, 1, T, 16, nullptr, xi, 6) : DVO_ERR_BAD_ARGUMENT; }
+int dvo_op_se3_concatenate(int dev, const float a[6], const float b[6], float out[6])
+{
+    return (a && b && out) ? se3_op(dev, 2, a, 6, b, out, 6) : DVO_ERR_BAD_ARGUMENT;
+}
+
+}  // extern "C"

@@ -1,0 +1,525 @@
+// dvo_engine.cpp -- host side of libdvo.so (see dvo_engine.h).  Reference citations: file:line under the reference tree.
+#include "dvo_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace dvo {
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_error;
+void set_error(const std::string& s) { g_error = s; }
+const char* last_error() { return g_error.c_str(); }
+
+int check_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return DVO_OK;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return DVO_ERR_NO_DEVICE;
+    if (e == hipErrorOutOfMemory) return DVO_ERR_OUT_OF_MEMORY;
+    return DVO_ERR_HIP;
+}
+
+int select_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: libdvo has no CPU fallback");
+        return DVO_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device ordinal out of range");
+        return DVO_ERR_BAD_ARGUMENT;
+    }
+    DVO_HIP(hipSetDevice(device));
+    return DVO_OK;
+}
+
+int DevBuf::alloc(size_t n)
+{
+    release();
+    if (n == 0) n = 4;
+    DVO_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return DVO_OK;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+static void cull_intrinsic(const float K[9], int times, float out[9])
+{  // Convert::cullIntrinsic, convert.cpp:22-29
+    if (times == 0) {
+        memcpy(out, K, 9 * sizeof(float));
+        return;
+    }
+    const double r = (double)(1 << times);
+    for (int i = 0; i < 9; i++) out[i] = (float)((double)K[i] / r);
+    out[8] = 1.0f;
+}
+
+int make_geometry(const float K[9], int w, int h, int levels, int culls, Geometry& g)
+{
+    if (levels < 1 || levels > DVO_MAX_LEVELS || culls < 0 || culls > 8 || w <= 0 || h <= 0) {
+        set_error("bad pyramid geometry");
+        return DVO_ERR_BAD_ARGUMENT;
+    }
+    g.src_w = w; g.src_h = h; g.levels = levels; g.culls = culls;
+    const int bw = w >> culls, bh = h >> culls;
+    float Kb[9];
+    cull_intrinsic(K, culls, Kb);
+    g.px_total = 0;
+    for (int i = 0; i < levels; i++) {
+        const int t = levels - 1 - i;  // frame.cpp:33-35
+        g.w[i] = bw >> t; g.h[i] = bh >> t;
+        if (g.w[i] < 1 || g.h[i] < 1) {
+            set_error("image too small for this many pyramid levels");
+            return DVO_ERR_BAD_ARGUMENT;
+        }
+        if ((size_t)g.w[i] * g.h[i] >= (1u << 24)) {
+            set_error("pyramid level larger than 2^24 pixels");
+            return DVO_ERR_BAD_ARGUMENT;
+        }
+        cull_intrinsic(Kb, t, g.K9[i]);
+        g.k[i] = Intr{g.K9[i][0], g.K9[i][4], g.K9[i][2], g.K9[i][5]};
+        g.px_total += (size_t)g.w[i] * g.h[i];
+    }
+    return DVO_OK;
+}
+
+int FrameSet::alloc(const Geometry& geo, int n)
+{
+    g = geo;
+    n_seq = n;
+    DVO_TRY(arena.alloc(3 * g.px_total * (size_t)n * sizeof(float)));
+    float* p = arena.as<float>();
+    for (int m = 0; m < 3; m++)
+        for (int l = 0; l < g.levels; l++) {
+            (m == 0 ? gray : m == 1 ? depth : sigma)[l] = p;
+            p += (size_t)g.w[l] * g.h[l] * n;
+        }
+    return DVO_OK;
+}
+
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s)
+{
+    PyramidArgs a;
+    memset(&a, 0, sizeof a);
+    a.src[0] = gray_dev; a.src[1] = depth_dev; a.src[2] = sigma_dev;
+    a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
+    for (int l = 0; l < fs.g.levels; l++) {
+        a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
+        a.dst[0][l] = fs.gray[l]; a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
+    }
+    a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
+    launch_pyramid(a, fs.n_seq, s);
+}
+
+void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s)
+{  // level i = cullImage(top, levels-1-i); the top level itself is the map handed in (frame.cpp:39-61)
+    PyramidArgs a;
+    memset(&a, 0, sizeof a);
+    const int T = fs.g.top();
+    a.src[1] = depth_top; a.src[2] = sigma_top;
+    a.src_w = fs.g.w[T]; a.src_h = fs.g.h[T]; a.culls = 0; a.levels = fs.g.levels;
+    for (int l = 0; l < fs.g.levels; l++) {
+        a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
+        a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
+    }
+    a.inv_tw = 1.0f / (float)fs.g.w[T];
+    launch_pyramid(a, fs.n_seq, s);
+}
+
+// ------------------------------------------------------------------------------------------------ tracker
+Tracker::~Tracker()
+{
+    for (auto& e : ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+}
+
+int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
+{
+    g = geo; n_seq = n; cfg = c;
+    if (cfg.max_iterations < 1 || cfg.max_iterations > DVO_MAX_ITERATIONS || cfg.fixed_iterations > DVO_MAX_ITERATIONS) {
+        set_error("iteration counts must be within [1, DVO_MAX_ITERATIONS]");
+        return DVO_ERR_BAD_ARGUMENT;
+    }
+    size_t max_part = 0;
+    for (int l = 0; l < g.levels; l++) {
+        int p = cfg.gn_pixels_per_thread;
+        if (p != 1 && p != 2 && p != 4 && p != 8) {  // auto: biggest tile that still gives >= 4 workgroups per CU
+            p = 8;
+            while (p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
+        }
+        ppt[l] = p;
+        nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p);
+        if ((size_t)nblk[l] > max_part) max_part = nblk[l];
+    }
+    DVO_TRY(state.alloc(sizeof(SeqState) * (size_t)n_seq));
+    DVO_TRY(partials.alloc(sizeof(float) * 32 * max_part * (size_t)n_seq));
+    DVO_TRY(log.alloc(sizeof(dvo_track_log) * (size_t)n_seq));
+    DVO_TRY(counters.alloc(2 * sizeof(unsigned long long)));
+    DVO_TRY(xi_out.alloc(sizeof(float) * 6 * (size_t)n_seq));
+    DVO_TRY(T_out.alloc(sizeof(float) * 16 * (size_t)n_seq));
+    DVO_HIP(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
+    DVO_HIP(hipMemset(log.p, 0, log.bytes));
+    return DVO_OK;
+}
+
+GnParams Tracker::level_params(int level) const
+{
+    GnParams p;
+    p.step = cfg.step_default;  // optimize.cpp:22-26
+    if (level == 1) p.step = cfg.step_level1;
+    if (level == 2) p.step = cfg.step_level2;
+    p.sigma_min = cfg.sigma_min; p.sigma_max = cfg.sigma_max;
+    p.min_depth = cfg.min_depth;
+    p.crop = (cfg.crop_enable && level == 2) ? 1 : 0;  // optimize.cpp:33-36
+    return p;
+}
+
+GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uint8_t* mask, int ignore_active) const
+{
+    GnArgs a;
+    a.obj_gray = obj.gray[level];
+    a.ref_gray = ref.gray[level];
+    a.ref_depth = ref.depth[level];
+    a.ref_sigma = ref.sigma[level];
+    a.state = state.as<SeqState>();
+    a.partials = partials.as<float>();
+    a.mask = mask;
+    a.w = g.w[level]; a.h = g.h[level]; a.nblk = nblk[level];
+    a.inv_w = 1.0f / (float)g.w[level];
+    a.k = g.k[level];
+    a.prm = level_params(level);
+    a.ignore_active = ignore_active;
+    return a;
+}
+
+int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
+{
+    launch_track_begin(state.as<SeqState>(), log.as<dvo_track_log>(), n_seq, g.levels, s);
+    const int max_it = cfg.fixed_iterations > 0 ? cfg.fixed_iterations : cfg.max_iterations;
+    // Small batches: every few iterations ask the device whether anything is still active, so a converged
+    // level does not pay for its remaining (empty) launches.  Big batches run the fixed schedule sync-free.
+    const bool poll = (cfg.fixed_iterations <= 0) && n_seq <= 8;
+    std::vector<SeqState> host_state;
+    if (poll) host_state.resize(n_seq);
+    for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
+        for (int it = 0; it < max_it; it++) {          // tracker.cpp:42
+            const int first = (it == 0) ? 1 : 0;
+            GnArgs ga = gn_args(obj, ref, level, nullptr, first);
+            if (cfg.profile) {
+                if (ev_used == ev_pool.size()) {
+                    hipEvent_t e0, e1;
+                    DVO_HIP(hipEventCreate(&e0));
+                    DVO_HIP(hipEventCreate(&e1));
+                    ev_pool.emplace_back(e0, e1);
+                }
+                DVO_HIP(hipEventRecord(ev_pool[ev_used].first, s));
+                launch_track_gn(ga, n_seq, ppt[level], s);
+                DVO_HIP(hipEventRecord(ev_pool[ev_used].second, s));
+                ev_used++;
+            } else {
+                launch_track_gn(ga, n_seq, ppt[level], s);
+            }
+            SolveArgs sa;
+            sa.state = state.as<SeqState>();
+            sa.partials = partials.as<float>();
+            sa.log = log.as<dvo_track_log>();
+            sa.result = nullptr;
+            sa.counters = cfg.profile ? counters.as<unsigned long long>() : nullptr;
+            sa.nblk = nblk[level]; sa.level = level; sa.level_pixels = g.w[level] * g.h[level];
+            sa.max_iterations = cfg.max_iterations; sa.fixed_iterations = cfg.fixed_iterations;
+            sa.min_update = cfg.min_update; sa.min_residual = cfg.min_residual;
+            sa.ignore_active = first;
+            launch_gn_solve(sa, n_seq, s);
+            if (poll && it + 1 < max_it) {
+                DVO_HIP(hipMemcpyAsync(host_state.data(), state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));
+                DVO_HIP(hipStreamSynchronize(s));
+                bool any = false;
+                for (int q = 0; q < n_seq; q++) any = any || host_state[q].active != 0;
+                if (!any) break;
+            }
+        }
+    }
+    launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s);
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int Tracker::collect_profile(hipStream_t s)
+{
+    DVO_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < ev_used; i++) {
+        float ms = 0;
+        DVO_HIP(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+        prof_ms += ms;
+        prof_launches++;
+    }
+    ev_used = 0;
+    return DVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ keyframes
+int Keyframe::alloc(const Geometry& g)
+{
+    DVO_TRY(fs.alloc(g, 1));
+    DVO_TRY(age.alloc(sizeof(float) * (size_t)g.w[g.top()] * g.h[g.top()]));
+    return DVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ VisualOdometry
+VisualOdometry::~VisualOdometry()
+{
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+int VisualOdometry::init(const float K9[9], int width, int height, const dvo_config* c)
+{
+    if (!K9 || width < 64 || height < 64) {
+        set_error("dvo_vo_create: bad K or frame size");
+        return DVO_ERR_BAD_ARGUMENT;
+    }
+    if (c) cfg = *c; else dvo_config_default(&cfg);
+    memcpy(K, K9, sizeof K);
+    w = width; h = height; device = cfg.device;
+    DVO_TRY(select_device(device));
+    if (cfg.stream) stream = (hipStream_t)cfg.stream;
+    else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
+    DVO_TRY(make_geometry(K, w, h, 3, 2, geoM));  // system.hpp:47
+    DVO_TRY(make_geometry(K, w, h, 4, 1, geoD));  // system.hpp:82
+    const size_t n = (size_t)w * h * sizeof(float);
+    DVO_TRY(in_gray.alloc(n)); DVO_TRY(in_depth.alloc(n)); DVO_TRY(in_sigma.alloc(n));
+    const size_t tn = (size_t)geoM.w[2] * geoM.h[2];
+    DVO_TRY(tmp_a.alloc(tn * 4)); DVO_TRY(tmp_b.alloc(tn * 4)); DVO_TRY(tmp_c.alloc(tn * 4));
+    DVO_TRY(owner.alloc(tn * 4));
+    DVO_TRY(valid_dev.alloc(sizeof(int)));
+    memset(&last_log, 0, sizeof last_log);
+    return DVO_OK;
+}
+
+static void default_initial_depth(int n, uint32_t seed, std::vector<float>& d, std::vector<float>& s)
+{  // stands in for cv::randn(depth, 1.5, 0.5); max(depth, 0.5); sigma = 0.5 (frame.hpp:17-21), deviation D6
+    d.resize(n); s.assign(n, 0.5f);
+    for (int i = 0; i < n; i++) {
+        const uint32_t a = mix32(seed ^ (uint32_t)(2 * i + 1) * 0x9E3779B9U), b = mix32(a ^ 0x85EBCA6BU);
+        const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+        const float z = std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2);
+        const float v = 1.5f + 0.5f * z;
+        d[i] = v < 0.5f ? 0.5f : v;
+    }
+}
+
+int VisualOdometry::init_keyframe(const float* gray, const float* depth, const float* sigma)
+{  // system.hpp:24-32 with the mono geometry (deviation D9)
+    if (!gray || !depth || !sigma) { set_error("null image"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const size_t n = (size_t)w * h * sizeof(float);
+    DVO_HIP(hipMemcpyAsync(in_gray.p, gray, n, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
+    auto kf = std::make_unique<Keyframe>();
+    DVO_TRY(kf->alloc(geoM));
+    kf->id = ++latest_id;
+    build_pyramid(kf->fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
+    DVO_HIP(hipMemsetAsync(kf->age.p, 0, kf->age.bytes, stream));
+    DVO_HIP(hipStreamSynchronize(stream));
+    hist.push_back(std::move(kf));
+    return DVO_OK;
+}
+
+int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
+{  // Mapper::propagate, mapper.cpp:62-74
+    const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
+    Pose pose;
+    pose_from_xi(frame.rel_xi, 1.0f, pose);
+    launch_propagate(ref.fs.depth[T], ref.fs.sigma[T], ref.age.as<float>(), tw, th, geoM.k[T], pose, frame.rel_xi[2],
+                     owner.as<int>(), frame.fs.depth[T], frame.fs.sigma[T], frame.age.as<float>(), stream);
+    redecimate(frame.fs, frame.fs.depth[T], frame.fs.sigma[T], stream);  // Frame::updateDepthSigmaAge, frame.cpp:47-54
+    return DVO_OK;
+}
+
+int VisualOdometry::map_update(Keyframe& obj)
+{  // Mapper::update, mapper.cpp:76-137
+    Keyframe& ref = *hist.back();
+    const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
+    const int n_hist = (int)hist.size();
+    std::vector<AgeEntry> tab(n_hist);
+    for (int i = 0; i < n_hist; i++) {  // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe
+        float nb[6], r_xi[6];
+        for (int k = 0; k < 6; k++) nb[k] = -hist[i]->xi[k];
+        se3_concatenate_f(obj.xi, nb, r_xi);
+        pose_from_xi(r_xi, -1.0f, tab[i].pose);
+        for (int k = 0; k < 3; k++) tab[i].tneg[k] = -r_xi[k];
+        tab[i].gray = hist[i]->fs.gray[T];
+    }
+    if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
+    DVO_HIP(hipMemcpyAsync(ages.p, tab.data(), sizeof(AgeEntry) * (size_t)n_hist, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemsetAsync(valid_dev.p, 0, sizeof(int), stream));
+    UpdateArgs a;
+    a.ref_depth = ref.fs.depth[T]; a.ref_sigma = ref.fs.sigma[T]; a.ref_age = ref.age.as<float>();
+    a.obj_gray = obj.fs.gray[T];
+    a.ages = ages.as<AgeEntry>();
+    a.n_hist = n_hist; a.w = tw; a.h = th; a.crop = cfg.crop_enable; a.obj_id = obj.id;
+    a.seed = cfg.rng_seed;
+    a.k = geoM.k[T];
+    memcpy(a.K9, geoM.K9[T], sizeof a.K9);
+    pose_from_xi(obj.rel_xi, 1.0f, a.rel_pose);
+    a.rel_tz = obj.rel_xi[2];
+    a.valid_updates = valid_dev.as<int>();
+    launch_depth_update(a, stream);
+    DVO_HIP(hipMemcpyAsync(&last_valid_updates, valid_dev.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));  // `tab` is pageable host memory: keep it alive until the copy is done
+    redecimate(ref.fs, ref.fs.depth[T], ref.fs.sigma[T], stream);  // mapper.cpp:135
+    return DVO_OK;
+}
+
+int VisualOdometry::map_regularize(Keyframe& kf)
+{  // Mapper::regularize, mapper.cpp:139-144
+    const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
+    launch_regularize(kf.fs.depth[T], kf.fs.sigma[T], tw, th, tmp_a.as<float>(), stream);
+    DVO_HIP(hipMemcpyAsync(kf.fs.depth[T], tmp_a.p, sizeof(float) * (size_t)tw * th, hipMemcpyDeviceToDevice, stream));
+    redecimate(kf.fs, kf.fs.depth[T], nullptr, stream);  // Frame::updateDepth, frame.cpp:56-61
+    return DVO_OK;
+}
+
+int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key)
+{  // system.hpp:44-74
+    if (!gray || !T_world) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    if (!trkM_ready) { DVO_TRY(trkM.init(geoM, 1, cfg)); trkM_ready = true; }
+    DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM)); }
+    Keyframe& frame = *scratch;
+    frame.id = ++latest_id;
+    for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
+    build_pyramid(frame.fs, in_gray.as<float>(), nullptr, nullptr, stream);
+    if (is_key) *is_key = 0;
+    const int T = geoM.top();
+    const size_t tn = (size_t)geoM.w[T] * geoM.h[T];
+    if (hist.empty()) {  // system.hpp:49-54
+        if (init_depth.empty()) default_initial_depth((int)tn, cfg.rng_seed, init_depth, init_sigma);
+        DVO_HIP(hipMemcpyAsync(frame.fs.depth[T], init_depth.data(), tn * 4, hipMemcpyHostToDevice, stream));
+        DVO_HIP(hipMemcpyAsync(frame.fs.sigma[T], init_sigma.data(), tn * 4, hipMemcpyHostToDevice, stream));
+        DVO_HIP(hipMemsetAsync(frame.age.p, 0, frame.age.bytes, stream));
+        redecimate(frame.fs, frame.fs.depth[T], frame.fs.sigma[T], stream);
+        DVO_HIP(hipStreamSynchronize(stream));
+        hist.push_back(std::move(scratch));
+        const float z[6] = {0, 0, 0, 0, 0, 0};
+        se3_exp_f(z, T_world);
+        if (is_key) *is_key = 1;
+        return DVO_OK;
+    }
+    Keyframe& ref = *hist.back();
+    DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
+    float rel[6];
+    DVO_HIP(hipMemcpyAsync(rel, trkM.xi_out.p, sizeof rel, hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipMemcpyAsync(&last_log, trkM.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));
+    memcpy(frame.rel_xi, rel, sizeof rel);  // Frame::updateXi, frame.cpp:7-14
+    frame.ref_id = ref.id;
+    se3_concatenate_f(ref.xi, rel, frame.xi);
+    // Mapper::estimate, mapper.cpp:16-33
+    const double tn2 = (double)rel[0] * rel[0] + (double)rel[1] * rel[1] + (double)rel[2] * rel[2];
+    const bool need = std::sqrt(tn2) > (double)cfg.keyframe_min_translation || (frame.id - ref.id >= cfg.keyframe_max_frames);  // mapper.cpp:45-60
+    memcpy(last_xi, frame.xi, sizeof last_xi);
+    memcpy(last_rel, frame.rel_xi, sizeof last_rel);
+    last_id = frame.id;
+    se3_exp_f(frame.xi, T_world);  // system.hpp:73
+    if (need) {
+        DVO_TRY(map_propagate(frame, ref));
+        hist.push_back(std::move(scratch));
+        if (is_key) *is_key = 1;
+    } else {
+        DVO_TRY(map_update(frame));
+    }
+    DVO_TRY(map_regularize(*hist.back()));  // mapper.cpp:26,30
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int VisualOdometry::odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16])
+{  // system.hpp:77-93
+    if (!gray || !depth || !sigma || !T_rel) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
+    const size_t n = (size_t)w * h * sizeof(float);
+    DVO_HIP(hipMemcpyAsync(in_gray.p, gray, n, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
+    if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD)); }
+    Keyframe& frame = *depth_cur;
+    frame.id = ++latest_id;
+    build_pyramid(frame.fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
+    const float z[6] = {0, 0, 0, 0, 0, 0};
+    if (!depth_ref) {  // system.hpp:83-86
+        for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
+        DVO_HIP(hipStreamSynchronize(stream));
+        depth_ref = std::move(depth_cur);
+        se3_exp_f(z, T_rel);
+        return DVO_OK;
+    }
+    DVO_TRY(trkD.track(frame.fs, depth_ref->fs, stream));
+    float rel[6];
+    DVO_HIP(hipMemcpyAsync(rel, trkD.xi_out.p, sizeof rel, hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipMemcpyAsync(T_rel, trkD.T_out.p, 16 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipMemcpyAsync(&last_log, trkD.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));
+    memcpy(frame.rel_xi, rel, sizeof rel);
+    frame.ref_id = depth_ref->id;
+    se3_concatenate_f(depth_ref->xi, rel, frame.xi);
+    memcpy(last_xi, frame.xi, sizeof last_xi);
+    memcpy(last_rel, rel, sizeof last_rel);
+    last_id = frame.id;
+    std::swap(depth_ref, depth_cur);  // m_ref_frame = frame, system.hpp:91
+    return DVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+Batch::~Batch()
+{
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+int Batch::init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c)
+{
+    if (n < 1 || !K9) { set_error("dvo_batch_create: bad arguments"); return DVO_ERR_BAD_ARGUMENT; }
+    if (c) cfg = *c; else dvo_config_default(&cfg);
+    n_seq = n; device = cfg.device;
+    DVO_TRY(select_device(device));
+    if (cfg.stream) stream = (hipStream_t)cfg.stream;
+    else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
+    DVO_TRY(make_geometry(K9, w, h, levels, culls, g));
+    DVO_TRY(fs[0].alloc(g, n));
+    DVO_TRY(fs[1].alloc(g, n));
+    DVO_TRY(trk.init(g, n, cfg));
+    return DVO_OK;
+}
+
+int Batch::push_device(const float* gray, const float* depth, const float* sigma)
+{
+    if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const int target = (cur < 0) ? 0 : (cur ^ 1);
+    build_pyramid(fs[target], gray, depth, sigma, stream);  // Frame(gray,depth,sigma,K,levels,culls)
+    if (cur >= 0) {
+        DVO_TRY(trk.track(fs[target], fs[cur], stream));    // system.hpp:88
+        have_poses = true;
+    }
+    cur = target;                                           // system.hpp:91
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+}  // namespace dvo

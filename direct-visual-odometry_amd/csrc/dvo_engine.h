@@ -1,0 +1,145 @@
+// dvo_engine.h -- C++ host side of libdvo.so: device memory, pyramids, the batched tracker and the
+// single-sequence VisualOdometry (tracking + mapping).  Mirrors the reference's classes:
+//   System::Frame / Scene  -> FrameSet (n_seq frames, one buffer per pyramid level)   include/system/frame.hpp
+//   Track::Tracker         -> Tracker                                                 src/track/tracker.cpp
+//   Map::Mapper            -> Mapper functions on Keyframe                             src/map/mapper.cpp
+//   System::VisualOdometry -> VisualOdometry                                           include/system/system.hpp
+// There is NO CPU fallback: every entry point fails with DVO_ERR_NO_DEVICE / DVO_ERR_HIP without a GPU.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "dvo_kernels.h"
+
+namespace dvo {
+
+void set_error(const std::string& s);
+const char* last_error();
+int check_hip(hipError_t e, const char* what);
+#define DVO_HIP(call)                                              \
+    do {                                                           \
+        int _st = ::dvo::check_hip((call), #call);                 \
+        if (_st != DVO_OK) return _st;                             \
+    } while (0)
+#define DVO_TRY(call)                                              \
+    do {                                                           \
+        int _st = (call);                                          \
+        if (_st != DVO_OK) return _st;                             \
+    } while (0)
+
+struct DevBuf {  // RAII hipMalloc
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Geometry {  // pyramid shape of Frame(gray, K, levels, culls): frame.hpp:91-117, frame.cpp:30-37
+    int src_w = 0, src_h = 0, levels = 0, culls = 0;
+    int w[DVO_MAX_LEVELS] = {0}, h[DVO_MAX_LEVELS] = {0};
+    float K9[DVO_MAX_LEVELS][9];
+    Intr k[DVO_MAX_LEVELS];
+    size_t px_total = 0;  // sum over levels of w*h
+    int top() const { return levels - 1; }
+};
+int make_geometry(const float K[9], int w, int h, int levels, int culls, Geometry& g);
+
+struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as [n_seq][h_l][w_l]
+    Geometry g;
+    int n_seq = 0;
+    DevBuf arena;
+    float* gray[DVO_MAX_LEVELS] = {nullptr};
+    float* depth[DVO_MAX_LEVELS] = {nullptr};
+    float* sigma[DVO_MAX_LEVELS] = {nullptr};
+    int alloc(const Geometry& geo, int n);
+};
+
+// Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s);
+// Frame::updateDepthSigma / updateDepth (frame.cpp:39-61): re-decimate from a top-level map (may alias the top level)
+void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s);
+
+struct Tracker {  // Track::Tracker for n_seq sequences at once
+    Geometry g;
+    int n_seq = 0;
+    dvo_config cfg;
+    DevBuf state, partials, log, counters, xi_out, T_out;
+    int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS];
+    // profiling (cfg.profile)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms = 0;
+    uint64_t prof_launches = 0;
+    ~Tracker();
+    int init(const Geometry& geo, int n, const dvo_config& c);
+    GnParams level_params(int level) const;
+    GnArgs gn_args(const FrameSet& obj, const FrameSet& ref, int level, uint8_t* mask, int ignore_active) const;
+    // Tracker::track (tracker.cpp:22-85): enqueue the whole coarse-to-fine loop; poses land in xi_out / T_out
+    int track(const FrameSet& obj, const FrameSet& ref, hipStream_t s);
+    int collect_profile(hipStream_t s);
+};
+
+struct Keyframe {  // System::Frame of one sequence, plus the age map and pose (frame.hpp:72-144)
+    FrameSet fs;
+    DevBuf age;    // top-level [h][w]
+    float xi[6] = {0, 0, 0, 0, 0, 0}, rel_xi[6] = {0, 0, 0, 0, 0, 0};
+    int id = -1, ref_id = -1;
+    int alloc(const Geometry& g);
+};
+
+struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
+    float K[9];
+    int w = 0, h = 0, device = 0;
+    dvo_config cfg;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Geometry geoM, geoD;  // Frame(gray,K,3,2) (system.hpp:47) and Frame(g,d,s,K,4,1) (system.hpp:82)
+    Tracker trkM, trkD;
+    bool trkM_ready = false, trkD_ready = false;
+    std::vector<std::unique_ptr<Keyframe>> hist;       // FrameHistory, oldest first
+    std::unique_ptr<Keyframe> scratch;                 // the frame being processed (promoted on keyframe)
+    std::unique_ptr<Keyframe> depth_ref, depth_cur;    // m_ref_frame of odometrizeUsingDepth
+    DevBuf in_gray, in_depth, in_sigma;                // full-resolution staging
+    DevBuf tmp_a, tmp_b, tmp_c, owner, ages, valid_dev;
+    std::vector<float> init_depth, init_sigma;
+    int latest_id = -1;                                // Frame::latest_id, frame.cpp:5
+    int last_id = -1, last_valid_updates = 0;
+    float last_xi[6] = {0}, last_rel[6] = {0};
+    dvo_track_log last_log;
+    ~VisualOdometry();
+    int init(const float K9[9], int width, int height, const dvo_config* c);
+    int odometrize(const float* gray, float T_world[16], int* is_key);
+    int odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16]);
+    int init_keyframe(const float* gray, const float* depth, const float* sigma);
+    int map_propagate(Keyframe& frame, const Keyframe& ref);
+    int map_update(Keyframe& obj);
+    int map_regularize(Keyframe& kf);
+};
+
+struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sensor depth
+    int n_seq = 0, device = 0;
+    dvo_config cfg;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Geometry g;
+    Tracker trk;
+    FrameSet fs[2];
+    int cur = -1;           // index of the reference frame set (-1: none yet)
+    bool have_poses = false;
+    DevBuf in_gray, in_depth, in_sigma;  // staging for push_host
+    ~Batch();
+    int init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c);
+    int push_device(const float* gray, const float* depth, const float* sigma);
+};
+
+int select_device(int device);
+
+}  // namespace dvo

@@ -1,0 +1,89 @@
+// dvo_kernels.h -- argument blocks and launch wrappers of the HIP kernels (dvo_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/dvo.h"
+#include "dvo_math.h"
+
+namespace dvo {
+
+// Per-sequence tracker state, resident on the device for the whole coarse-to-fine loop.
+struct SeqState {
+    float xi[6];   // current relative twist (tracker.cpp:28,48)
+    Pose  pose;    // exp(-xi) rounded to float: what every warp of the level uses
+    int   active;  // 0 once the level's stop test fired (tracker.cpp:68-73)
+    int   iter;    // iterations done on the current level
+};
+
+struct PyramidArgs {
+    const float* src[3];               // gray, depth, sigma at input resolution [n_seq][src_h][src_w] (nullptr = skip)
+    float* dst[3][DVO_MAX_LEVELS];     // per map, per level [n_seq][h][w]
+    int src_w, src_h, culls, levels;
+    int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS];
+    float inv_tw;                      // 1 / top-level width
+};
+
+struct GnArgs {
+    const float* obj_gray;   // level buffers [n_seq][h][w]
+    const float* ref_gray;
+    const float* ref_depth;
+    const float* ref_sigma;
+    const SeqState* state;
+    float* partials;         // [n_seq][nblk][32]
+    uint8_t* mask;           // optional [n_seq][h][w], pre-zeroed
+    int w, h, nblk;
+    float inv_w;
+    Intr k;
+    GnParams prm;
+    int ignore_active;       // 1 on the first iteration of a level / probes
+};
+
+struct SolveArgs {
+    SeqState* state;
+    const float* partials;
+    dvo_track_log* log;        // optional [n_seq]
+    dvo_gn_result* result;     // optional [n_seq]
+    unsigned long long* counters;  // optional: [0] += level_pixels, [1] += 1 per solved sequence-iteration
+    int nblk, level, level_pixels;
+    int max_iterations, fixed_iterations;
+    float min_update, min_residual;
+    int ignore_active;         // 1 on the first iteration of a level: every sequence restarts (iter = 0)
+};
+
+struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)
+    Pose  pose;        // exp(-r_xi), r_xi = concatenate(obj.xi, -born.xi)
+    float tneg[3];     // -r_xi[0:3] (twist part; implement.cpp:56)
+    const float* gray; // born keyframe's top-level gray
+};
+
+struct UpdateArgs {
+    float* ref_depth; float* ref_sigma; float* ref_age;   // in place (top level of the reference keyframe)
+    const float* obj_gray;
+    const AgeEntry* ages;    // [n_hist], index = history index (oldest first)
+    int n_hist, w, h, crop, obj_id;
+    uint32_t seed;
+    Intr k;
+    float K9[9];
+    Pose rel_pose;           // exp(+rel_xi)
+    float rel_tz;            // rel_xi[2]
+    int* valid_updates;
+};
+
+void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s);
+void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s);
+void launch_gradient(const float* img, int w, int h, int xdir, float* out, hipStream_t s);
+void launch_warp_image(const float* gray, const float* depth, int w, int h, const Intr& k, const Pose& pose, float* out, hipStream_t s);
+int  gn_blocks_per_seq(int w, int h, int ppt);
+void launch_track_gn(const GnArgs& a, int n_seq, int ppt, hipStream_t s);
+void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s);
+void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s);
+void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_t s);
+void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s);
+void launch_se3(int op, const float* a, const float* b, float* out, hipStream_t s);
+void launch_propagate(const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h, const Intr& k,
+                      const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s);
+void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s);
+void launch_depth_update(const UpdateArgs& a, hipStream_t s);
+
+}  // namespace dvo

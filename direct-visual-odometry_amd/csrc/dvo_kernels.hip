@@ -1,0 +1,613 @@
+// dvo_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the direct-VO hot path.
+//
+// wave64, 256-thread workgroups, no MFMA (the path is HBM/VALU-bound image warping).
+// Reductions are fixed-order (DPP row_shr / row_bcast inside a wave, LDS across the 4 waves, double
+// across workgroups) so every run is bit-reproducible.  Built with -ffp-contract=off: only the fmaf()
+// calls written in dvo_math.h fuse.
+#include <hip/hip_runtime.h>
+
+#include "dvo_kernels.h"
+
+namespace dvo {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+// XCD-aware bijective remap of the linear workgroup id: workgroups b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD one contiguous range of tiles -> neighbouring tiles of an image (which share
+// gather rows of ref_gray) hit the same 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// wave64 sum, result valid in lane 63.  Classic GCN scan: row_shr 1,2,4,8 inside each row of 16 lanes,
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.  Fixed order => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ void split_index(int i, int w, float inv_w, int& x, int& y)
+{  // i < 2^24: y = i / w without an integer divide
+    y = (int)((float)i * inv_w);
+    x = i - y * w;
+    if (x < 0) { y -= 1; x += w; }
+    else if (x >= w) { y += 1; x -= w; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pyramid: System::Frame pyramid (frame.hpp:91-117, frame.cpp:16-37) = nearest-neighbour decimation
+// (Convert::cullImage, convert.cpp:7-20) of up to three maps, all levels in ONE launch.
+// One thread per TOP-level pixel reads src(x<<culls, y<<culls) once and writes every level it lands on
+// (level t shifts below the top keep pixels whose coordinates are multiples of 2^t).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
+{
+    const int seq = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
+    if (i >= tw * th) return;
+    int x, y;
+    split_index(i, tw, a.inv_tw, x, y);
+    const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << a.culls) * a.src_w + (x << a.culls);
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        if (a.src[m] == nullptr) continue;
+        const float raw = a.src[m][src_off];
+        const float pv = pass_valid(raw);
+        // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
+        a.dst[m][a.levels - 1][(size_t)seq * tw * th + i] = (a.culls > 0) ? pv : raw;
+        for (int t = 1; t < a.levels; t++) {
+            const int msk = (1 << t) - 1;
+            if ((x & msk) | (y & msk)) break;
+            const int l = a.levels - 1 - t, lx = x >> t, ly = y >> t;
+            if (lx < a.w[l] && ly < a.h[l]) a.dst[m][l][(size_t)seq * a.w[l] * a.h[l] + ly * a.w[l] + lx] = pv;
+        }
+    }
+}
+
+// k_cull: a single Convert::cullImage (operator-level parity)
+__global__ void __launch_bounds__(256) k_cull(const float* __restrict__ src, int w, int h, int times, float* __restrict__ dst)
+{
+    const int dw = w >> times, dh = h >> times;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dw * dh) return;
+    const int y = i / dw, x = i - y * dw;
+    const float raw = src[(size_t)(y << times) * w + (x << times)];
+    dst[i] = times > 0 ? pass_valid(raw) : raw;
+}
+
+// k_gradient: Convert::gradiate (convert.cpp:41-75), standalone parity op
+__global__ void __launch_bounds__(256) k_gradient(const float* __restrict__ img, int w, int h, int xdir, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    GlobalImg g{img, w, h};
+    out[i] = xdir ? grad_x_at(g, x, y) : grad_y_at(g, x, y);
+}
+
+// k_warp_image: Transform::warpImage (transform.cpp:35-51), standalone parity/visual op.  The fused tracker
+// never materialises this image.
+__global__ void __launch_bounds__(256) k_warp_image(const float* __restrict__ gray, const float* __restrict__ depth,
+                                                    int w, int h, Intr k, Pose pose, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const float d = depth[i];
+    float v = kInvalid;
+    if (!is_epsilon(d)) {
+        float pu, pv;
+        warp(pose, k, (float)x, (float)y, d, pu, pv);
+        GlobalImg g{gray, w, h};
+        v = get_subpixel(g, pu, pv);
+    }
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_track_gn: the fused Gauss-Newton accumulation = Transform::warpImage + Track::optimize's per-pixel
+// lambda (optimize.cpp:28-90) + the A^T A / A^T B products that cv::solve's SVD stands for.
+//
+// HBM traffic per evaluated pixel: obj_gray 4 + ref_depth 4 + ref_sigma 4 (coalesced rows) + ref_gray 4
+// (12-tap plus-shaped gather around the warped position, served by L1/L2 or the LDS patch) = 16 B.
+// Each thread owns PPT pixels (stride 256 => coalesced), keeps 29 accumulators (21 upper-tri J^T J, 6 J^T wr,
+// sum r^2, count), then: DPP wave sum -> LDS across the 4 waves -> one 32-float partial per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct Acc29 {
+    float a[29];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int i = 0; i < 29; i++) a[i] = 0.0f;
+    }
+    __device__ __forceinline__ void add(const float J[6], float r, float rw)
+    {
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p; q < 6; q++) {
+                a[idx] = fmaf(J[p], J[q], a[idx]);
+                idx++;
+            }
+#pragma unroll
+        for (int p = 0; p < 6; p++) a[21 + p] = fmaf(J[p], rw, a[21 + p]);
+        a[27] = fmaf(r, r, a[27]);
+        a[28] += 1.0f;
+    }
+};
+
+template <int PPT>
+__global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
+{
+    __shared__ float red[4][32];
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int seq = id / a.nblk, blk = id - seq * a.nblk;
+    const SeqState& st = a.state[seq];
+    if (!a.ignore_active && st.active == 0) return;  // converged sequences cost nothing
+    const Pose pose = st.pose;                        // wave-uniform -> scalar loads
+    const size_t img_off = (size_t)seq * a.w * a.h;
+    const float* __restrict__ obj = a.obj_gray + img_off;
+    const float* __restrict__ dep = a.ref_depth + img_off;
+    const float* __restrict__ sig = a.ref_sigma + img_off;
+    const GlobalImg ref{a.ref_gray + img_off, a.w, a.h};
+    const int npix = a.w * a.h;
+    const int base = blk * (256 * PPT) + threadIdx.x;
+
+    Acc29 acc;
+    acc.zero();
+    float d[PPT], I1[PPT], sg[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {  // issue the coalesced loads first
+        const int i = base + k * 256;
+        const bool in = i < npix;
+        d[k] = in ? dep[i] : 0.0f;
+        I1[k] = in ? obj[i] : kInvalid;
+        sg[k] = in ? sig[i] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = base + k * 256;
+        if (i >= npix) continue;
+        int x, y;
+        split_index(i, a.w, a.inv_w, x, y);
+        float J[6], r, rw;
+        if (gn_pixel(ref, a.k, pose, a.prm, x, y, d[k], I1[k], sg[k], J, r, rw)) {
+            acc.add(J, r, rw);
+            if (a.mask) a.mask[img_off + i] = 1;
+        }
+    }
+    // wave reduction (DPP), then 4 waves through LDS in fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 29; c++) {
+        const float s = wave_sum_to_lane63(acc.a[c]);
+        if (lane == 63) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        float s = 0.0f;
+        if (c < 29) s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        a.partials[((size_t)seq * a.nblk + blk) * 32 + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gn_solve: second reduction stage + the rest of one Tracker::track iteration (tracker.cpp:44-73),
+// one 64-thread workgroup per sequence, entirely on the device:
+//   partial sums -> double, fixed order;  xi_update = H^+ g (LDL^T / eigen pseudo-inverse, double);
+//   xi <- log(exp(xi) exp(xi_update)) unless NaN (testXi);  pose <- exp(-xi);  stop tests.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_gn_solve(SolveArgs a)
+{
+    __shared__ double tot[32];
+    const int seq = blockIdx.x;
+    SeqState& st = a.state[seq];
+    if (!a.ignore_active && st.active == 0) return;
+    const int c = threadIdx.x;
+    if (c < 32) {
+        double s = 0.0;
+        if (c < 29) {
+            const float* p = a.partials + (size_t)seq * a.nblk * 32 + c;
+            for (int b = 0; b < a.nblk; b++) s += (double)p[(size_t)b * 32];
+        }
+        tot[c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    const int n_valid = (int)tot[28];
+    const double sum_r2 = tot[27];
+    float upd[6] = {0, 0, 0, 0, 0, 0};
+    float residual = -1.0f;  // optimize.cpp:92-93
+    if (n_valid > 0) {
+        solve6(tot, tot + 21, upd);
+        residual = (float)sum_r2 / (float)n_valid;  // optimize.cpp:98
+    }
+    float xi[6], nxt[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
+    se3_concatenate_f(xi, upd, nxt);  // tracker.cpp:46
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) ok = ok && !(nxt[i] != nxt[i]);  // testXi, util.hpp:34-44
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { xi[i] = nxt[i]; st.xi[i] = nxt[i]; }
+        pose_from_xi(xi, -1.0f, st.pose);  // Stuff::update -> warp with -xi (optimize.hpp:26-30)
+    }
+    double nrm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) nrm += (double)upd[i] * (double)upd[i];
+    nrm = sqrt(nrm);
+
+    const int it = a.ignore_active ? 0 : st.iter;
+    if (a.log && it < DVO_MAX_ITERATIONS) {
+        dvo_track_log& lg = a.log[seq];
+        lg.n_iter[a.level] = it + 1;
+        lg.residual[a.level][it] = residual;
+        lg.update_norm[a.level][it] = (float)nrm;
+        lg.n_valid[a.level][it] = n_valid;
+#pragma unroll
+        for (int i = 0; i < 6; i++) lg.xi_after[a.level][it][i] = xi[i];
+    }
+    if (a.result) {  // operator-level output (dvo_op_gn_step)
+        dvo_gn_result& r = a.result[seq];
+        for (int i = 0; i < 21; i++) r.H[i] = tot[i];
+        for (int i = 0; i < 6; i++) { r.g[i] = tot[21 + i]; r.xi_update[i] = upd[i]; r.xi_next[i] = xi[i]; }
+        r.sum_r2 = sum_r2;
+        r.n_valid = n_valid;
+        r.residual = residual;
+    }
+    st.iter = it + 1;
+    int active = 1;
+    if (a.fixed_iterations > 0) {
+        active = (it + 1 < a.fixed_iterations) ? 1 : 0;
+    } else if (nrm < (double)a.min_update || residual < a.min_residual || it + 1 >= a.max_iterations) {
+        active = 0;  // tracker.cpp:68-73 (the wall-clock term is disabled, D1)
+    }
+    st.active = active;
+    if (a.counters) {  // profile: evaluated pixels / sequence-iterations
+        atomicAdd(&a.counters[0], (unsigned long long)a.level_pixels);
+        atomicAdd(&a.counters[1], 1ull);
+    }
+}
+
+// k_track_begin: Tracker::track line 28 (xi = 0) for every sequence
+__global__ void __launch_bounds__(256) k_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seq) return;
+    SeqState& st = state[s];
+    for (int i = 0; i < 6; i++) st.xi[i] = 0.0f;
+    for (int i = 0; i < 9; i++) st.pose.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 3; i++) st.pose.t[i] = 0.0f;
+    st.active = 1;
+    st.iter = 0;
+    if (log) {
+        log[s].levels = levels;
+        for (int l = 0; l < DVO_MAX_LEVELS; l++) log[s].n_iter[l] = 0;
+    }
+}
+
+// k_set_pose: load a caller-supplied twist (operator-level gn_step / probes)
+__global__ void k_set_pose(SeqState* state, const float* xi, int n_seq)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seq) return;
+    float x[6];
+    for (int i = 0; i < 6; i++) { x[i] = xi[s * 6 + i]; state[s].xi[i] = x[i]; }
+    pose_from_xi(x, -1.0f, state[s].pose);
+    state[s].active = 1;
+    state[s].iter = 0;
+}
+
+// k_export_poses: relative twist + exp(xi) 4x4 (system.hpp:92) per sequence
+__global__ void k_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seq) return;
+    float x[6], T[16];
+    for (int i = 0; i < 6; i++) { x[i] = state[s].xi[i]; xi_out[s * 6 + i] = x[i]; }
+    se3_exp_f(x, T);
+    for (int i = 0; i < 16; i++) T_out[s * 16 + i] = T[i];
+}
+
+// k_se3: device evaluation of the double-precision pose algebra (parity op): op 0 exp, 1 log, 2 concatenate
+__global__ void k_se3(int op, const float* in_a, const float* in_b, float* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (op == 0) {
+        float xi[6], T[16];
+        for (int i = 0; i < 6; i++) xi[i] = in_a[i];
+        se3_exp_f(xi, T);
+        for (int i = 0; i < 16; i++) out[i] = T[i];
+    } else if (op == 1) {
+        float T[16], xi[6];
+        for (int i = 0; i < 16; i++) T[i] = in_a[i];
+        se3_log_f(T, xi);
+        for (int i = 0; i < 6; i++) out[i] = xi[i];
+    } else {
+        float x[6], y[6], o[6];
+        for (int i = 0; i < 6; i++) { x[i] = in_a[i]; y[i] = in_b[i]; }
+        se3_concatenate_f(x, y, o);
+        for (int i = 0; i < 6; i++) out[i] = o[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mapping kernels (src/map/implement.cpp)
+// ------------------------------------------------------------------------------------------------
+// Implement::propagate (implement.cpp:217-256).  The reference's forEach scatter races; its sequential
+// semantics are "last writer in raster order wins" (D7).  Three passes reproduce that exactly:
+//   pass 0: outputs <- (1, 1, 0), owner <- -1;  pass 1: owner[target] = max(source index);
+//   pass 2: every target pulls depth/sigma/age from its owning source pixel.
+__global__ void __launch_bounds__(256) k_propagate_init(float* depth, float* sigma, float* age, int* owner, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    depth[i] = 1.0f; sigma[i] = 1.0f; age[i] = 0.0f; owner[i] = -1;
+}
+
+__global__ void __launch_bounds__(256) k_propagate_owner(const float* __restrict__ ref_depth, int w, int h, Intr k, Pose pose, int* owner)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const float rd = ref_depth[i];
+    if (is_epsilon(rd)) return;
+    float pu, pv;
+    warp(pose, k, (float)x, (float)y, rd, pu, pv);
+    int qx, qy;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
+    atomicMax(&owner[qy * w + qx], i);
+}
+
+__global__ void __launch_bounds__(256) k_propagate_pull(const float* __restrict__ ref_depth, const float* __restrict__ ref_sigma,
+                                                        const float* __restrict__ ref_age, const int* __restrict__ owner, int n, float tz,
+                                                        float* depth, float* sigma, float* age)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    const int i = owner[o];
+    if (i < 0) return;
+    const float rd = ref_depth[i];
+    float s = ref_sigma[i];
+    const float d0 = rd < 0.01f ? 0.01f : rd;
+    const float d1 = d0 + tz;
+    const float q = d1 / d0;
+    const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
+    s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
+    depth[o] = d1 < 0.0f ? 0.0f : d1;
+    sigma[o] = s;
+    age[o] = ref_age[i] + 1.0f;
+}
+
+// Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
+__global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ depth, const float* __restrict__ sigma, int w, int h, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    float gd = depth[i], gs = sigma[i];
+    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
+    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
+    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
+    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
+    out[i] = gd < 6.0f ? gd : 6.0f;
+}
+
+// Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per
+// reference pixel.  FP32-VALU / gather-latency bound (<= 102 search steps x 3 bilinear samples), not HBM
+// bound.  The per-age relative poses are precomputed on the host (never a per-pixel exp/log).
+__global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int w = a.w, h = a.h;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    if (a.crop && (x < 16 || x > 144 || y < 12 || y > 108)) return;  // mapper.cpp:90
+    const float d = a.ref_depth[i];
+    float pu, pv;
+    warp(a.rel_pose, a.k, (float)x, (float)y, d, pu, pv);             // mapper.cpp:94
+    int qx, qy;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
+    const int age = (int)a.ref_age[i];                                 // mapper.cpp:99
+    const int bi = a.n_hist - 1 - age;                                 // frame.hpp:176
+    if (bi < 0 || bi >= a.n_hist) return;
+    const AgeEntry& born = a.ages[bi];
+    const float depth = d - a.rel_tz;                                  // mapper.cpp:104
+    const float sigma = a.ref_sigma[i];
+    const GlobalImg bg{born.gray, w, h};
+    // EpipolarSegment, implement.cpp:23-47
+    const float dmin = (depth - sigma) < 0.10f ? 0.10f : (depth - sigma);
+    const float dmax = depth + sigma;
+    float sx, sy, ex, ey;
+    warp(born.pose, a.k, (float)qx, (float)qy, dmax, sx, sy);
+    warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
+    const float sex = sx - ex, sey = sy - ey;
+    const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
+    // doMatching, implement.cpp:106-152
+    const float og = a.obj_gray[qy * w + qx];
+    const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
+    float ptx = sx, pty = sy, bestx = sx, besty = sy, min_ssd = 6.0f;
+    int count = 0;
+    for (;;) {
+        const float ddx = ptx - sx, ddy = pty - sy;
+        if (!(sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy) < (double)length)) break;
+        float ssd = 0.0f;
+        ptx += dirx;
+        pty += diry;
+        for (int j = 0; j < 3; j++) {
+            const float kf = (float)(j - 1);
+            const float tx = ptx + dirx * kf, ty = pty + diry * kf;
+            const float sgv = get_subpixel_dense(bg, tx, ty);
+            if (is_invalid(sgv)) { ssd = 6.0f; break; }
+            const float diff = sgv - og;
+            const int aw = 3 - abs(j - 2);
+            ssd = (float)((double)ssd + 1.0 * aw / 3 * (double)(diff * diff));  // implement.cpp:134
+        }
+        if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
+        if (count++ > 100) break;
+    }
+    if ((double)min_ssd > 3 * 0.1) return;                             // implement.cpp:145
+    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return;  // implement.cpp:196-200
+    // depthEstimate, implement.cpp:49-71 (double from float inputs)
+    float nd;
+    {
+        float q0f, q1f, q2f;
+        back_project(a.k, (float)qx, (float)qy, 1.0f, q0f, q1f, q2f);
+        const double q0 = q0f, q1 = q1f, q2 = q2f;
+        const double t[3] = {(double)born.tneg[0], (double)born.tneg[1], (double)born.tneg[2]};
+        const double xi3[3] = {(double)bestx, (double)besty, 1.0};
+        double Rq[3], KRq[3], Kt[3];
+        for (int r = 0; r < 3; r++)
+            Rq[r] = (double)born.pose.R[3 * r] * q0 + (double)born.pose.R[3 * r + 1] * q1 + (double)born.pose.R[3 * r + 2] * q2;
+        for (int r = 0; r < 3; r++) {
+            KRq[r] = (double)a.K9[3 * r] * Rq[0] + (double)a.K9[3 * r + 1] * Rq[1] + (double)a.K9[3 * r + 2] * Rq[2];
+            Kt[r] = (double)a.K9[3 * r] * t[0] + (double)a.K9[3 * r + 1] * t[1] + (double)a.K9[3 * r + 2] * t[2];
+        }
+        double aa = 0.0, ab = 0.0;
+        for (int r = 0; r < 3; r++) {
+            const double va = Rq[2] * xi3[r] - KRq[r];
+            const double vb = t[2] * xi3[r] - Kt[r];
+            aa += va * va;
+            ab += va * vb;
+        }
+        nd = -(float)(ab / aa);
+    }
+    // sigmaEstimate, implement.cpp:73-104
+    float ns;
+    {
+        const float l = length;
+        const float lx = sex / l, ly = sey / l;
+        const float alpha = (dmax - dmin) / l;
+        int mx = 0, my = 0;
+        round_coord(bestx, mx);
+        round_coord(besty, my);
+        mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
+        my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
+        const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
+        if (is_invalid(gx) || is_invalid(gy)) return;  // new_sigma = -1 fails the gate of mapper.cpp:122
+        const float gl = fabsf(fmaf(gy, ly, gx * lx));
+        const float gl2 = gl * gl, gp2 = gl / l;
+        const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
+        const float lum = 0.5f / (gp2 < kEpsilon ? kEpsilon : gp2);
+        ns = alpha * sqrtf(epi + lum);
+    }
+    if (nd > 0.2f && nd < 6.0f && ns > 0.0f && ns < 0.5f) {            // mapper.cpp:122
+        float gd = depth, gs = sigma;
+        const float reset = rng_depth(a.seed, (uint32_t)a.obj_id, (uint32_t)i);
+        if (!gaussian_update(gd, gs, nd, ns, reset)) a.ref_age[i] = 0.0f;  // mapper.cpp:124-127
+        else atomicAdd(a.valid_updates, 1);
+        a.ref_depth[i] = gd;                                           // mapper.cpp:130-131
+        a.ref_sigma[i] = gs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (host)
+// ------------------------------------------------------------------------------------------------
+static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s)
+{
+    const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
+    hipLaunchKernelGGL(k_pyramid, dim3(cdiv(tw * th, 256), n_seq), dim3(256), 0, s, a);
+}
+
+void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s)
+{
+    const int n = (w >> times) * (h >> times);
+    hipLaunchKernelGGL(k_cull, dim3(cdiv(n, 256)), dim3(256), 0, s, src, w, h, times, dst);
+}
+
+void launch_gradient(const float* img, int w, int h, int xdir, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gradient, dim3(cdiv(w * h, 256)), dim3(256), 0, s, img, w, h, xdir, out);
+}
+
+void launch_warp_image(const float* gray, const float* depth, int w, int h, const Intr& k, const Pose& pose, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_warp_image, dim3(cdiv(w * h, 256)), dim3(256), 0, s, gray, depth, w, h, k, pose, out);
+}
+
+int gn_blocks_per_seq(int w, int h, int ppt) { return (int)cdiv((unsigned)(w * h), 256u * (unsigned)ppt); }
+
+void launch_track_gn(const GnArgs& a, int n_seq, int ppt, hipStream_t s)
+{
+    const dim3 grid((unsigned)a.nblk * (unsigned)n_seq), block(256);
+    switch (ppt) {
+        case 1: hipLaunchKernelGGL(k_track_gn<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_track_gn<2>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(k_track_gn<4>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(k_track_gn<8>, grid, block, 0, s, a); break;
+    }
+}
+
+void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(64), 0, s, a);
+}
+
+void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_track_begin, dim3(cdiv(n_seq, 256)), dim3(256), 0, s, state, log, n_seq, levels);
+}
+
+void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_pose, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, state, xi_dev, n_seq);
+}
+
+void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_export_poses, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, state, xi_out, T_out, n_seq);
+}
+
+void launch_se3(int op, const float* a, const float* b, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_se3, dim3(1), dim3(64), 0, s, op, a, b, out);
+}
+
+void launch_propagate(const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h, const Intr& k,
+                      const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s)
+{
+    const int n = w * h;
+    hipLaunchKernelGGL(k_propagate_init, dim3(cdiv(n, 256)), dim3(256), 0, s, depth, sigma, age, owner, n);
+    hipLaunchKernelGGL(k_propagate_owner, dim3(cdiv(n, 256)), dim3(256), 0, s, ref_depth, w, h, k, pose, owner);
+    hipLaunchKernelGGL(k_propagate_pull, dim3(cdiv(n, 256)), dim3(256), 0, s, ref_depth, ref_sigma, ref_age, owner, n, tz, depth, sigma, age);
+}
+
+void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_regularize, dim3(cdiv(w * h, 256)), dim3(256), 0, s, depth, sigma, w, h, out);
+}
+
+void launch_depth_update(const UpdateArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_depth_update, dim3(cdiv(a.w * a.h, 256)), dim3(256), 0, s, a);
+}
+
+}  // namespace dvo

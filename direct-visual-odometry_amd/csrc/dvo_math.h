@@ -1,0 +1,472 @@
+// dvo_math.h -- per-pixel arithmetic and SE(3) algebra shared by the HIP kernels and the C++ host code.
+//
+// The float operation order written here IS the contract of DESIGN.md §3: every multi-term sum is an
+// explicit fmaf chain and the translation unit is compiled with -ffp-contract=off, so the CDNA4 VALU
+// and an x86 host evaluate bit-identical per-pixel values.  SE(3) exp/log run in double and are rounded
+// to float once (deviation D2).  Reference citations are file:line under the reference tree.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DVO_HD __host__ __device__ __forceinline__
+#else
+#define DVO_HD inline
+#endif
+
+namespace dvo {
+
+constexpr float kInvalid = -2.0f;  // include/math/util.hpp:7
+constexpr float kEpsilon = 1e-6f;  // include/math/util.hpp:6
+
+struct Intr {  // fx, fy, cx, cy of a pyramid level (Convert::cullIntrinsic, src/core/convert.cpp:22-29)
+    float fx, fy, cx, cy;
+};
+
+struct Pose {  // R (row major) and t of exp(+-xi), rounded to float once
+    float R[9];
+    float t[3];
+};
+
+DVO_HD bool is_valid(float v) { return kInvalid < v; }      // util.hpp:9
+DVO_HD bool is_invalid(float v) { return v <= kInvalid; }   // util.hpp:10
+DVO_HD bool is_epsilon(float v) { return fabsf(v) < kEpsilon; }  // util.hpp:29-32
+DVO_HD bool coord_ok(float v) { return fabsf(v) < 1073741824.0f; }  // D4: false for NaN/inf/huge
+
+// ---------------------------------------------------------------- geometry, src/core/transform.cpp:20-33
+DVO_HD void back_project(const Intr& k, float px, float py, float d, float& X, float& Y, float& Z)
+{
+    X = (d * (px - k.cx)) / k.fx;
+    Y = (d * (py - k.cy)) / k.fy;
+    Z = d;
+}
+
+DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float& Yo, float& Zo)
+{
+    Xo = fmaf(p.R[0], X, fmaf(p.R[1], Y, fmaf(p.R[2], Z, p.t[0])));
+    Yo = fmaf(p.R[3], X, fmaf(p.R[4], Y, fmaf(p.R[5], Z, p.t[1])));
+    Zo = fmaf(p.R[6], X, fmaf(p.R[7], Y, fmaf(p.R[8], Z, p.t[2])));
+}
+
+DVO_HD void project(const Intr& k, float X, float Y, float Z, float& u, float& v)
+{
+    u = (X * k.fx) / Z + k.cx;
+    v = (Y * k.fy) / Z + k.cy;
+}
+
+DVO_HD void warp(const Pose& p, const Intr& k, float px, float py, float d, float& u, float& v)
+{
+    float X, Y, Z, Xw, Yw, Zw;
+    back_project(k, px, py, d, X, Y, Z);
+    transform(p, X, Y, Z, Xw, Yw, Zw);
+    project(k, Xw, Yw, Zw, u, v);
+}
+
+// ---------------------------------------------------------------- sampling, src/core/convert.cpp
+DVO_HD float blend4(float g0, float g1, float g2, float g3, float hx, float vy)
+{
+    const float omh = 1.0f - hx, omv = 1.0f - vy;
+    const float top = fmaf(g1, hx, g0 * omh);
+    const float bot = fmaf(g3, hx, g2 * omh);
+    return fmaf(bot, vy, top * omv);
+}
+
+// Convert::getPixel semantics (convert.cpp:107-125) for an in-range index: invalid (or NaN) -> INVALID
+DVO_HD float pass_valid(float g) { return is_valid(g) ? g : kInvalid; }
+
+// The fill loop of Convert::getSubpixel (convert.cpp:155-173), literally.  Returns false for "all invalid".
+DVO_HD bool fill_quirk(float g[4])
+{
+    if (is_valid(g[0]) && is_valid(g[1]) && is_valid(g[2]) && is_valid(g[3])) return true;  // common case
+    int valid = 0, id = 0;
+    float last = -1.0f;
+    for (int guard = 0; guard < 16; ++guard) {
+        if (is_valid(g[id])) {
+            valid++;
+            last = g[id];
+        } else if (last > 0.0f) {
+            g[id] = last;
+            valid++;
+        }
+        if (valid == 4) return true;
+        if (id == 3 && valid == 0) return false;
+        id = (id + 1) & 3;
+    }
+    return true;  // unreachable: every pass adds at least one
+}
+
+// Generic image accessor used by the samplers: Img must provide  float at(int x, int y) const, int w, h.
+struct GlobalImg {
+    const float* p;
+    int w, h;
+    DVO_HD float at(int x, int y) const { return p[y * w + x]; }
+};
+
+template <class Img>
+DVO_HD bool load_taps(const Img& img, float px, float py, float g[4], float& hx, float& vy)
+{  // convert.cpp:82-101 / 133-153: truncation toward zero, missing taps clamp to g00
+    if (!coord_ok(px) || !coord_ok(py)) return false;
+    const int x0 = (int)px, y0 = (int)py;
+    if (x0 < 0 || img.w <= x0 || y0 < 0 || img.h <= y0) return false;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    hx = px - (float)x0;
+    vy = py - (float)y0;
+    const float g00 = img.at(x0, y0);
+    g[0] = g00;
+    g[1] = (x1 < img.w) ? img.at(x1, y0) : g00;
+    g[2] = (y1 < img.h) ? img.at(x0, y1) : g00;
+    g[3] = (x1 < img.w && y1 < img.h) ? img.at(x1, y1) : g00;
+    return true;
+}
+
+template <class Img>
+DVO_HD float get_subpixel(const Img& img, float px, float py)
+{  // convert.cpp:128-177
+    float g[4], hx, vy;
+    if (!load_taps(img, px, py, g, hx, vy)) return kInvalid;
+    if (!fill_quirk(g)) return kInvalid;
+    return blend4(g[0], g[1], g[2], g[3], hx, vy);
+}
+
+template <class Img>
+DVO_HD float get_subpixel_dense(const Img& img, float px, float py)
+{  // convert.cpp:77-105
+    float g[4], hx, vy;
+    if (!load_taps(img, px, py, g, hx, vy)) return kInvalid;
+    return blend4(g[0], g[1], g[2], g[3], hx, vy);
+}
+
+// Convert::gradiate at one pixel (convert.cpp:41-75), derived from the gray image on the fly.
+template <class Img>
+DVO_HD float grad_x_at(const Img& img, int x, int y)
+{
+    if (x - 1 <= -1 || x + 1 >= img.w) return kInvalid;
+    const float a = img.at(x - 1, y), b = img.at(x + 1, y);
+    if (!is_valid(a) || !is_valid(b)) return kInvalid;
+    return b - a;
+}
+template <class Img>
+DVO_HD float grad_y_at(const Img& img, int x, int y)
+{
+    if (y - 1 <= -1 || y + 1 >= img.h) return kInvalid;
+    const float a = img.at(x, y - 1), b = img.at(x, y + 1);
+    if (!is_valid(a) || !is_valid(b)) return kInvalid;
+    return b - a;
+}
+
+// getSubpixelFromDense(grad_x / grad_y, p) with the gradient maps derived on the fly.  p is already known to
+// be inside [0,w) x [0,h) (optimize.cpp:52-56), so (x0,y0) is in range.
+template <class Img>
+DVO_HD void grad_subpixel(const Img& img, float px, float py, float& gx, float& gy)
+{
+    const int x0 = (int)px, y0 = (int)py;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float hx = px - (float)x0, vy = py - (float)y0;
+    const bool inx = x1 < img.w, iny = y1 < img.h;
+    const float gx00 = grad_x_at(img, x0, y0), gy00 = grad_y_at(img, x0, y0);
+    const float gx10 = inx ? grad_x_at(img, x1, y0) : gx00, gy10 = inx ? grad_y_at(img, x1, y0) : gy00;
+    const float gx01 = iny ? grad_x_at(img, x0, y1) : gx00, gy01 = iny ? grad_y_at(img, x0, y1) : gy00;
+    const float gx11 = (inx && iny) ? grad_x_at(img, x1, y1) : gx00, gy11 = (inx && iny) ? grad_y_at(img, x1, y1) : gy00;
+    gx = blend4(gx00, gx10, gx01, gx11, hx, vy);
+    gy = blend4(gy00, gy10, gy01, gy11, hx, vy);
+}
+
+// ---------------------------------------------------------------- one pixel of Track::optimize (optimize.cpp:28-90)
+struct GnParams {
+    float step;        // optimize.cpp:22-26
+    float sigma_min, sigma_max;  // optimize.cpp:83
+    float min_depth;   // optimize.cpp:39
+    int   crop;        // 1 when this level is cropped (optimize.cpp:33-36)
+};
+
+// Returns true when the pixel contributes; J[6], r (residual) and rw (weighted residual) are then set.
+template <class Img>
+DVO_HD bool gn_pixel(const Img& ref_gray, const Intr& k, const Pose& pose, const GnParams& prm, int x, int y,
+                     float d, float I1, float sigma, float J[6], float& r, float& rw)
+{
+    if (prm.crop && (x < 20 || x > 140 || y < 20 || y > 100)) return false;
+    if (d < prm.min_depth) return false;  // (double)d < 0.20  <=>  d < 0.2f for float d
+    float u, v;
+    warp(pose, k, (float)x, (float)y, d, u, v);
+    // warped_gray(x) = getSubpixel(ref_gray, warp(-xi, x, d)) (transform.cpp:35-51); d >= min_depth so never epsilon
+    const float I2 = is_epsilon(d) ? kInvalid : get_subpixel(ref_gray, u, v);
+    if (is_invalid(I1) || is_invalid(I2)) return false;
+    if (u < 0.0f || v < 0.0f || (float)ref_gray.w <= u || (float)ref_gray.h <= v) return false;
+    if (!coord_ok(u) || !coord_ok(v)) return false;  // D4 (NaN passes the comparisons above)
+    float gx, gy;
+    grad_subpixel(ref_gray, u, v, gx, gy);
+    if (is_invalid(gx) || is_invalid(gy)) return false;
+    float X, Y, Z;
+    back_project(k, (float)x, (float)y, d, X, Y, Z);
+    const float fgx = k.fx * gx, fgy = k.fy * gy;
+    const float xz = X / Z, yz = Y / Z;
+    J[0] = fgx / Z;
+    J[1] = fgy / Z;
+    J[2] = ((-fmaf(fgy, Y, fgx * X)) / Z) / Z;
+    J[3] = -(((fgx * xz) * yz) + (fgy * fmaf(yz, yz, 1.0f)));
+    J[4] = (fgx * fmaf(xz, xz, 1.0f)) + ((fgy * xz) * yz);
+    J[5] = fmaf(fgy, xz, -(fgx * yz));
+    r = I2 - I1;
+    const float sc = sigma < prm.sigma_min ? prm.sigma_min : (prm.sigma_max < sigma ? prm.sigma_max : sigma);
+    rw = r * (prm.step / sc);
+    return true;
+}
+
+// ---------------------------------------------------------------- SE(3) in double, src/math/se3.cpp
+DVO_HD void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+DVO_HD void se3_exp_d(const double xi[6], double R[9], double t[3])
+{  // se3.cpp:70-98 with so3::exp = cv::Rodrigues
+    const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    double c = 1.0, s = 0.0;
+    if (th < 2.220446049250313e-16) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    } else {
+        c = cos(th);
+        s = sin(th);
+        const double c1 = 1.0 - c, rx = w[0] / th, ry = w[1] / th, rz = w[2] / th;
+        R[0] = c + c1 * rx * rx;      R[1] = c1 * rx * ry - s * rz; R[2] = c1 * rx * rz + s * ry;
+        R[3] = c1 * rx * ry + s * rz; R[4] = c + c1 * ry * ry;      R[5] = c1 * ry * rz - s * rx;
+        R[6] = c1 * rx * rz - s * ry; R[7] = c1 * ry * rz + s * rx; R[8] = c + c1 * rz * rz;
+    }
+    if ((float)th > 1e-6f) {
+        const double A = (1.0 - c) / th2, B = (th - s) / (th2 * th);
+        double wv[3], wwv[3];
+        cross3(w, v, wv);
+        cross3(w, wv, wwv);
+        for (int i = 0; i < 3; i++) t[i] = v[i] + A * wv[i] + B * wwv[i];
+    } else {
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2];
+    }
+}
+
+DVO_HD void se3_log_d(const double R[9], const double t[3], double xi[6])
+{  // se3.cpp:31-43, 101-124; theta via atan2 (same angle as acos((tr-1)/2), no NaN by rounding)
+    const double a[3] = {0.5 * (R[7] - R[5]), 0.5 * (R[2] - R[6]), 0.5 * (R[3] - R[1])};
+    const double s = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const double cth = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+    const double th = atan2(s, cth);
+    double w[3] = {0, 0, 0};
+    if ((float)th > 1e-6f && s > 0.0) {
+        const double k = th / s;
+        w[0] = a[0] * k; w[1] = a[1] * k; w[2] = a[2] * k;
+    }
+    const double wl2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double wl = sqrt(wl2);
+    double v[3] = {t[0], t[1], t[2]};
+    if ((float)wl > 1e-6f) {
+        const double half = 0.5 * wl;
+        const double coef = (1.0 - (wl * cos(half)) / (2.0 * sin(half))) / wl2;
+        double wt[3], wwt[3];
+        cross3(w, t, wt);
+        cross3(w, wt, wwt);
+        for (int i = 0; i < 3; i++) v[i] = t[i] - 0.5 * wt[i] + coef * wwt[i];
+    }
+    xi[0] = v[0]; xi[1] = v[1]; xi[2] = v[2]; xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+
+DVO_HD void se3_concatenate_f(const float a[6], const float b[6], float out[6])
+{  // se3.cpp:127-131: log(exp(a) exp(b))
+    double xa[6], xb[6], Ra[9], ta[3], Rb[9], tb[3], R[9], t[3], x[6];
+    for (int i = 0; i < 6; i++) { xa[i] = a[i]; xb[i] = b[i]; }
+    se3_exp_d(xa, Ra, ta);
+    se3_exp_d(xb, Rb, tb);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) R[3 * r + c] = Ra[3 * r] * Rb[c] + Ra[3 * r + 1] * Rb[3 + c] + Ra[3 * r + 2] * Rb[6 + c];
+        t[r] = Ra[3 * r] * tb[0] + Ra[3 * r + 1] * tb[1] + Ra[3 * r + 2] * tb[2] + ta[r];
+    }
+    se3_log_d(R, t, x);
+    for (int i = 0; i < 6; i++) out[i] = (float)x[i];
+}
+
+DVO_HD void pose_from_xi(const float xi[6], float sign, Pose& p)
+{
+    double x[6], R[9], t[3];
+    for (int i = 0; i < 6; i++) x[i] = (double)sign * (double)xi[i];
+    se3_exp_d(x, R, t);
+    for (int i = 0; i < 9; i++) p.R[i] = (float)R[i];
+    for (int i = 0; i < 3; i++) p.t[i] = (float)t[i];
+}
+
+DVO_HD void se3_exp_f(const float xi[6], float T[16])
+{
+    Pose p;
+    pose_from_xi(xi, 1.0f, p);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T[4 * r + c] = p.R[3 * r + c];
+        T[4 * r + 3] = p.t[r];
+    }
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+DVO_HD void se3_log_f(const float T[16], float xi[6])
+{
+    double R[9], t[3], x[6];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
+        t[r] = T[4 * r + 3];
+    }
+    se3_log_d(R, t, x);
+    for (int i = 0; i < 6; i++) xi[i] = (float)x[i];
+}
+
+// ---------------------------------------------------------------- 6x6 solve: x = H^+ g  (replaces cv::solve(A,-B,SVD), optimize.cpp:96-98)
+DVO_HD void jacobi_eig6(double A[36], double V[36])
+{
+    for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < 6; i++) {
+            diag += A[7 * i] * A[7 * i];
+            for (int j = i + 1; j < 6; j++) off += A[6 * i + j] * A[6 * i + j];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[6 * p + q];
+                if (apq == 0.0) continue;
+                const double tau = (A[7 * q] - A[7 * p]) / (2.0 * apq);
+                const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), s = tt * c;
+                for (int k = 0; k < 6; k++) {
+                    const double akp = A[6 * k + p], akq = A[6 * k + q];
+                    A[6 * k + p] = c * akp - s * akq;
+                    A[6 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double apk = A[6 * p + k], aqk = A[6 * q + k];
+                    A[6 * p + k] = c * apk - s * aqk;
+                    A[6 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = V[6 * k + p], vkq = V[6 * k + q];
+                    V[6 * k + p] = c * vkp - s * vkq;
+                    V[6 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// H: 21 upper-triangle entries row major.  Fast path LDL^T; a pivot <= 1e-12 * max diag switches to the
+// eigen pseudo-inverse with cv::solve(DECOMP_SVD)'s cut (sqrt(lambda) <= 2 FLT_EPSILON sum sqrt(lambda) dropped).
+DVO_HD void solve6(const double H[21], const double g[6], float x[6])
+{
+    double A[36];
+    {
+        int k = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) {
+                A[6 * i + j] = H[k];
+                A[6 * j + i] = H[k];
+                k++;
+            }
+    }
+    double maxd = 0;
+    for (int i = 0; i < 6; i++) maxd = A[7 * i] > maxd ? A[7 * i] : maxd;
+    for (int i = 0; i < 6; i++) x[i] = 0.0f;
+    if (!(maxd > 0.0)) return;
+    double L[36], d[6], y[6], z[6];
+    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    bool ok = true;
+    for (int j = 0; j < 6 && ok; j++) {
+        double dj = A[7 * j];
+        for (int k = 0; k < j; k++) dj -= L[6 * j + k] * L[6 * j + k] * d[k];
+        if (!(dj > 1e-12 * maxd)) { ok = false; break; }
+        d[j] = dj;
+        L[7 * j] = 1.0;
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[6 * i + j];
+            for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k] * d[k];
+            L[6 * i + j] = v / dj;
+        }
+    }
+    if (ok) {
+        for (int i = 0; i < 6; i++) {
+            double v = g[i];
+            for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
+            y[i] = v;
+        }
+        for (int i = 0; i < 6; i++) y[i] /= d[i];
+        for (int i = 5; i >= 0; i--) {
+            double v = y[i];
+            for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * z[k];
+            z[i] = v;
+        }
+        for (int i = 0; i < 6; i++) x[i] = (float)z[i];
+        return;
+    }
+    double V[36], sv[6], sum = 0;
+    jacobi_eig6(A, V);
+    for (int i = 0; i < 6; i++) {
+        sv[i] = sqrt(A[7 * i] > 0.0 ? A[7 * i] : 0.0);
+        sum += sv[i];
+    }
+    const double thr = 2.0 * 1.1920928955078125e-07 * sum;
+    for (int i = 0; i < 6; i++) z[i] = 0;
+    for (int i = 0; i < 6; i++) {
+        if (!(sv[i] > thr)) continue;
+        double proj = 0;
+        for (int k = 0; k < 6; k++) proj += V[6 * k + i] * g[k];
+        proj /= A[7 * i];
+        for (int k = 0; k < 6; k++) z[k] += V[6 * k + i] * proj;
+    }
+    for (int i = 0; i < 6; i++) x[i] = (float)z[i];
+}
+
+// ---------------------------------------------------------------- Gaussian fusion, src/math/gaussian.cpp
+DVO_HD uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+// D3: replaces dist(engine) of gaussian.cpp:8-9,22: uniform_real_distribution<float>(2.0, 0.5) then min(.,4)
+DVO_HD float rng_depth(uint32_t seed, uint32_t frame_id, uint32_t pixel)
+{
+    const uint32_t h = mix32(mix32(seed ^ (frame_id * 0x9E3779B9U)) ^ (pixel * 0x85EBCA6BU) ^ 0x68E31DA4U);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    const float v = fmaf(u, -1.5f, 2.0f);
+    return v < 4.0f ? v : 4.0f;
+}
+
+DVO_HD float gauss_gain(float d, float diff)
+{  // gaussian.cpp:20
+    const float m = d < diff ? d : diff;
+    return (m < 0.8f) ? 0.5f + (m / 0.8f) * 0.5f : 1.0f;  // (double)m < 0.8  <=>  m < 0.8f (0.8f > 0.8)
+}
+
+DVO_HD bool gaussian_fuse(float& depth, float& sigma, float d, float s)
+{  // gaussian.cpp:33-50
+    const float v1 = sigma * sigma, v2 = s * s, v = v1 + v2;
+    const float diff = fabsf(d - depth);
+    const float gain = gauss_gain(d, diff);
+    const float ms = sigma < s ? s : sigma;
+    if (diff > gain * ms) return false;
+    depth = fmaf(v1, d, v2 * depth) / v;
+    sigma = sqrtf((v1 * v2) / v);
+    return true;
+}
+
+DVO_HD bool gaussian_update(float& depth, float& sigma, float d, float s, float reset_depth)
+{  // gaussian.cpp:12-31
+    if (gaussian_fuse(depth, sigma, d, s)) return true;
+    depth = reset_depth;
+    sigma = 0.5f;
+    return false;
+}
+
+DVO_HD bool round_coord(float v, int& out)
+{  // cv::Point2f -> cv::Point2i = cvRound (round half to even), with D4
+    if (!coord_ok(v)) return false;
+    out = (int)rintf(v);
+    return true;
+}
+
+}  // namespace dvo

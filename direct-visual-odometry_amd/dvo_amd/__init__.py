@@ -1,0 +1,377 @@
+"""ctypes binding of libdvo.so (include/dvo.h): the MI355X-native direct-VO hot path.
+
+The names mirror the reference's interface for this path (include/system/system.hpp, include/track/*.hpp,
+include/map/implement.hpp, include/core/{convert,transform}.hpp) so the parity tests read like the
+reference's own demos.  There is NO CPU fallback: if lib/libdvo.so is missing, or no GPU is visible when a
+compute entry point is called, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdvo.so")
+INVALID = np.float32(-2.0)
+MAX_LEVELS = 8
+MAX_ITERATIONS = 32
+FP = C.POINTER(C.c_float)
+
+
+class DvoError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("min_update", C.c_float), ("min_residual", C.c_float),
+                ("fixed_iterations", C.c_int), ("crop_enable", C.c_int), ("step_default", C.c_float),
+                ("step_level1", C.c_float), ("step_level2", C.c_float), ("sigma_min", C.c_float),
+                ("sigma_max", C.c_float), ("min_depth", C.c_float), ("keyframe_min_translation", C.c_float),
+                ("keyframe_max_frames", C.c_int), ("rng_seed", C.c_uint32), ("device", C.c_int),
+                ("stream", C.c_void_p), ("profile", C.c_int), ("gn_pixels_per_thread", C.c_int),
+                ("gn_use_lds_patch", C.c_int)]
+
+
+class TrackLog(C.Structure):
+    _fields_ = [("levels", C.c_int), ("n_iter", C.c_int * MAX_LEVELS),
+                ("residual", (C.c_float * MAX_ITERATIONS) * MAX_LEVELS),
+                ("update_norm", (C.c_float * MAX_ITERATIONS) * MAX_LEVELS),
+                ("n_valid", (C.c_int * MAX_ITERATIONS) * MAX_LEVELS),
+                ("xi_after", ((C.c_float * 6) * MAX_ITERATIONS) * MAX_LEVELS)]
+
+    def to_dict(self):
+        L = self.levels
+        out = dict(n_iter=[self.n_iter[l] for l in range(L)], residual=[], upd_norm=[], n_valid=[], xi_after=[])
+        for l in range(L):
+            n = self.n_iter[l]
+            out["residual"].append(np.array(self.residual[l][:n], np.float32))
+            out["upd_norm"].append(np.array(self.update_norm[l][:n], np.float32))
+            out["n_valid"].append(np.array(self.n_valid[l][:n], np.int32))
+            out["xi_after"].append(np.array([self.xi_after[l][i][:] for i in range(n)], np.float32).reshape(n, 6))
+        return out
+
+
+class GnResult(C.Structure):
+    _fields_ = [("H", C.c_double * 21), ("g", C.c_double * 6), ("sum_r2", C.c_double), ("n_valid", C.c_int),
+                ("xi_update", C.c_float * 6), ("residual", C.c_float), ("xi_next", C.c_float * 6)]
+
+
+class GnProfile(C.Structure):
+    _fields_ = [("gn_ms", C.c_double), ("gn_launches", C.c_uint64), ("gn_pixels", C.c_uint64),
+                ("gn_iterations", C.c_uint64)]
+
+
+EXPORTS = [
+    "dvo_config_default", "dvo_version", "dvo_status_string", "dvo_last_error", "dvo_device_count",
+    "dvo_vo_create", "dvo_vo_destroy", "dvo_vo_set_initial_depth", "dvo_vo_init_keyframe", "dvo_vo_odometrize",
+    "dvo_vo_odometrize_depth", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
+    "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
+    "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
+    "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
+    "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
+    "dvo_op_propagate", "dvo_op_regularize", "dvo_op_depth_update", "dvo_op_se3_exp", "dvo_op_se3_log",
+    "dvo_op_se3_concatenate",
+]
+
+_lib = None
+
+
+def lib():
+    """Load lib/libdvo.so.  Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DvoError("libdvo.so not built: run `make -C direct-visual-odometry_amd` (or __graft_entry__.build()); "
+                           "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.dvo_version.restype = C.c_char_p
+        L.dvo_status_string.restype = C.c_char_p
+        L.dvo_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(st):
+    if st != 0:
+        L = lib()
+        raise DvoError("%s: %s" % (L.dvo_status_string(st).decode(), L.dvo_last_error().decode()))
+
+
+def default_config(**kw):
+    c = Config()
+    lib().dvo_config_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def fp(a):
+    return a.ctypes.data_as(FP)
+
+
+def device_count():
+    return lib().dvo_device_count()
+
+
+# ------------------------------------------------------------------ math::se3 (device evaluated)
+class se3:
+    @staticmethod
+    def exp(xi, dev=0):
+        xi = f32(xi); T = np.zeros(16, np.float32)
+        _check(lib().dvo_op_se3_exp(dev, fp(xi), fp(T)))
+        return T.reshape(4, 4)
+
+    @staticmethod
+    def log(T, dev=0):
+        T = f32(T).reshape(16); xi = np.zeros(6, np.float32)
+        _check(lib().dvo_op_se3_log(dev, fp(T), fp(xi)))
+        return xi
+
+    @staticmethod
+    def concatenate(a, b, dev=0):
+        a = f32(a); b = f32(b); o = np.zeros(6, np.float32)
+        _check(lib().dvo_op_se3_concatenate(dev, fp(a), fp(b), fp(o)))
+        return o
+
+
+# ------------------------------------------------------------------ Convert / Transform
+class Convert:
+    @staticmethod
+    def cullImage(src, times, dev=0):
+        src = f32(src); h, w = src.shape
+        dst = np.zeros((h >> times, w >> times), np.float32)
+        _check(lib().dvo_op_cull_image(dev, fp(src), w, h, times, fp(dst)))
+        return dst
+
+    @staticmethod
+    def gradiate(img, x, dev=0):
+        img = f32(img); h, w = img.shape
+        out = np.zeros((h, w), np.float32)
+        _check(lib().dvo_op_gradient(dev, fp(img), w, h, 1 if x else 0, fp(out)))
+        return out
+
+
+class Transform:
+    @staticmethod
+    def warpImage(xi, gray, depth, K, dev=0):
+        xi = f32(xi); gray = f32(gray); depth = f32(depth); K = f32(K).reshape(9)
+        h, w = gray.shape
+        out = np.zeros((h, w), np.float32)
+        _check(lib().dvo_op_warp_image(dev, fp(xi), fp(gray), fp(depth), w, h, fp(K), fp(out)))
+        return out
+
+
+def pyramid(gray, depth, sigma, levels, culls, dev=0):
+    """Frame(gray, depth, sigma, K, levels, culls) pyramids (frame.cpp:16-37): lists of per-level arrays."""
+    gray = f32(gray); h, w = gray.shape
+    d = f32(depth) if depth is not None else None
+    s = f32(sigma) if sigma is not None else None
+    shapes = [((h >> culls) >> (levels - 1 - i), (w >> culls) >> (levels - 1 - i)) for i in range(levels)]
+    go = [np.zeros(sh, np.float32) for sh in shapes]
+    do = [np.zeros(sh, np.float32) for sh in shapes]
+    so = [np.zeros(sh, np.float32) for sh in shapes]
+    arr = lambda lst: (FP * levels)(*[fp(a) for a in lst])
+    _check(lib().dvo_op_pyramid(dev, fp(gray), fp(d) if d is not None else None, fp(s) if s is not None else None,
+                                w, h, levels, culls, arr(go), arr(do), arr(so)))
+    return go, (do if d is not None else None), (so if s is not None else None)
+
+
+# ------------------------------------------------------------------ Track
+def optimize(obj_gray, ref_gray, ref_depth, ref_sigma, K, xi, level, cfg=None, want_mask=False, dev=0):
+    """Track::optimize (src/track/optimize.cpp:10-99): one Gauss-Newton step on one level."""
+    obj_gray = f32(obj_gray); ref_gray = f32(ref_gray); ref_depth = f32(ref_depth); ref_sigma = f32(ref_sigma)
+    K = f32(K).reshape(9); xi = f32(xi)
+    h, w = ref_gray.shape
+    out = GnResult()
+    mask = np.zeros((h, w), np.uint8) if want_mask else None
+    _check(lib().dvo_op_gn_step(dev, C.byref(cfg) if cfg is not None else None, fp(obj_gray), fp(ref_gray),
+                                fp(ref_depth), fp(ref_sigma), w, h, fp(K), fp(xi), level, C.byref(out),
+                                mask.ctypes.data_as(C.c_void_p) if want_mask else None))
+    res = dict(H=np.array(out.H[:]), g=np.array(out.g[:]), sum_r2=out.sum_r2, n_valid=out.n_valid,
+               xi_update=np.array(out.xi_update[:], np.float32), residual=np.float32(out.residual),
+               xi_next=np.array(out.xi_next[:], np.float32))
+    if want_mask:
+        res["mask"] = mask
+    return res
+
+
+def track(obj_gray, ref_gray, ref_depth, ref_sigma, K, levels, culls, cfg=None, dev=0):
+    """Tracker::track (src/track/tracker.cpp:22-85) on full-resolution frames."""
+    obj_gray = f32(obj_gray); ref_gray = f32(ref_gray); ref_depth = f32(ref_depth); ref_sigma = f32(ref_sigma)
+    K = f32(K).reshape(9)
+    h, w = ref_gray.shape
+    xi = np.zeros(6, np.float32); log = TrackLog()
+    _check(lib().dvo_op_track(dev, C.byref(cfg) if cfg is not None else None, fp(obj_gray), fp(ref_gray),
+                              fp(ref_depth), fp(ref_sigma), w, h, fp(K), levels, culls, fp(xi), C.byref(log)))
+    return xi, log.to_dict()
+
+
+# ------------------------------------------------------------------ Map::Implement
+class Implement:
+    @staticmethod
+    def propagate(ref_depth, ref_sigma, ref_age, xi, K, dev=0):
+        d = f32(ref_depth); s = f32(ref_sigma); a = f32(ref_age); xi = f32(xi); K = f32(K).reshape(9)
+        h, w = d.shape
+        od = np.zeros_like(d); os_ = np.zeros_like(d); oa = np.zeros_like(d)
+        _check(lib().dvo_op_propagate(dev, fp(d), fp(s), fp(a), w, h, fp(xi), fp(K), fp(od), fp(os_), fp(oa)))
+        return od, os_, oa
+
+    @staticmethod
+    def regularize(depth, sigma, dev=0):
+        d = f32(depth); s = f32(sigma); h, w = d.shape
+        out = np.zeros_like(d)
+        _check(lib().dvo_op_regularize(dev, fp(d), fp(s), w, h, fp(out)))
+        return out
+
+
+def mapper_update(hist_gray, hist_xi, obj_gray, obj_xi, obj_rel_xi, obj_id, K, ref_depth, ref_sigma, ref_age,
+                  cfg=None, dev=0):
+    """Mapper::update (src/map/mapper.cpp:76-137).  Returns updated (depth, sigma, age, valid_updates)."""
+    n = len(hist_gray)
+    grays = [f32(g) for g in hist_gray]
+    h, w = grays[0].shape
+    garr = (FP * n)(*[fp(g) for g in grays])
+    hx = f32(np.asarray(hist_xi).reshape(n, 6))
+    og = f32(obj_gray); ox = f32(obj_xi); orx = f32(obj_rel_xi); K = f32(K).reshape(9)
+    d = f32(ref_depth).copy(); s = f32(ref_sigma).copy(); a = f32(ref_age).copy()
+    v = C.c_int(0)
+    _check(lib().dvo_op_depth_update(dev, C.byref(cfg) if cfg is not None else None, n, garr, fp(hx), fp(og), fp(ox),
+                                     fp(orx), int(obj_id), fp(K), w, h, fp(d), fp(s), fp(a), C.byref(v)))
+    return d, s, a, v.value
+
+
+# ------------------------------------------------------------------ System::VisualOdometry
+class VisualOdometry:
+    """System::VisualOdometry (include/system/system.hpp:12-104)."""
+
+    def __init__(self, K, width, height, cfg=None):
+        K = f32(K).reshape(9)
+        self.width, self.height = width, height
+        self._p = C.c_void_p()
+        _check(lib().dvo_vo_create(fp(K), width, height, C.byref(cfg) if cfg is not None else None, C.byref(self._p)))
+
+    def close(self):
+        if self._p:
+            lib().dvo_vo_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setInitialDepth(self, depth, sigma):
+        d = f32(depth); s = f32(sigma)
+        _check(lib().dvo_vo_set_initial_depth(self._p, fp(d), fp(s)))
+
+    def initKeyframe(self, gray, depth, sigma):
+        g = f32(gray); d = f32(depth); s = f32(sigma)
+        _check(lib().dvo_vo_init_keyframe(self._p, fp(g), fp(d), fp(s)))
+
+    def odometrize(self, gray):
+        g = f32(gray); T = np.zeros(16, np.float32); key = C.c_int(0)
+        _check(lib().dvo_vo_odometrize(self._p, fp(g), fp(T), C.byref(key)))
+        return T.reshape(4, 4), bool(key.value)
+
+    def odometrizeUsingDepth(self, gray, depth, sigma):
+        g = f32(gray); d = f32(depth); s = f32(sigma); T = np.zeros(16, np.float32)
+        _check(lib().dvo_vo_odometrize_depth(self._p, fp(g), fp(d), fp(s), fp(T)))
+        return T.reshape(4, 4)
+
+    def keyframeCount(self):
+        return lib().dvo_vo_keyframe_count(self._p)
+
+    def keyframeInfo(self, index):
+        i = C.c_int(); l = C.c_int(); w = C.c_int(); h = C.c_int()
+        xi = np.zeros(6, np.float32); rel = np.zeros(6, np.float32)
+        _check(lib().dvo_vo_keyframe_info(self._p, index, C.byref(i), C.byref(l), C.byref(w), C.byref(h), fp(xi), fp(rel)))
+        return dict(id=i.value, levels=l.value, width=w.value, height=h.value, xi=xi, rel_xi=rel)
+
+    def keyframe(self, index, level=None):
+        info = self.keyframeInfo(index)
+        top = info["levels"] - 1
+        if level is None:
+            level = top
+        sh = (info["height"] >> (top - level), info["width"] >> (top - level))
+        g = np.zeros(sh, np.float32); d = np.zeros(sh, np.float32); s = np.zeros(sh, np.float32)
+        a = np.zeros(sh, np.float32) if level == top else None
+        K = np.zeros(9, np.float32)
+        _check(lib().dvo_vo_keyframe_get(self._p, index, level, fp(g), fp(d), fp(s), fp(a) if a is not None else None, fp(K)))
+        return dict(gray=g, depth=d, sigma=s, age=a, K=K.reshape(3, 3), **info)
+
+    def lastFramePose(self):
+        i = C.c_int(); xi = np.zeros(6, np.float32); rel = np.zeros(6, np.float32)
+        _check(lib().dvo_vo_last_frame_pose(self._p, C.byref(i), fp(xi), fp(rel)))
+        return i.value, xi, rel
+
+    def lastValidUpdates(self):
+        return lib().dvo_vo_last_valid_updates(self._p)
+
+    def lastTrackLog(self):
+        log = TrackLog()
+        _check(lib().dvo_vo_last_track_log(self._p, C.byref(log)))
+        return log.to_dict()
+
+
+# ------------------------------------------------------------------ batched tracking (n_seq sequences per GPU)
+class Batch:
+    def __init__(self, n_seq, K, width, height, levels=4, culls=1, cfg=None):
+        K = f32(K).reshape(9)
+        self.n_seq, self.width, self.height, self.levels, self.culls = n_seq, width, height, levels, culls
+        self._p = C.c_void_p()
+        _check(lib().dvo_batch_create(n_seq, fp(K), width, height, levels, culls,
+                                      C.byref(cfg) if cfg is not None else None, C.byref(self._p)))
+
+    def close(self):
+        if self._p:
+            lib().dvo_batch_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push_device(self, gray_ptr, depth_ptr, sigma_ptr):
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()) to [n_seq, H, W] float32."""
+        _check(lib().dvo_batch_push_device(self._p, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), C.c_void_p(sigma_ptr)))
+
+    def push_host(self, gray, depth, sigma):
+        g = f32(gray); d = f32(depth); s = f32(sigma)
+        assert g.shape == (self.n_seq, self.height, self.width)
+        _check(lib().dvo_batch_push_host(self._p, fp(g), fp(d), fp(s)))
+
+    def last_poses(self):
+        xi = np.zeros((self.n_seq, 6), np.float32); T = np.zeros((self.n_seq, 16), np.float32)
+        _check(lib().dvo_batch_last_poses(self._p, fp(xi), fp(T)))
+        return xi, T.reshape(self.n_seq, 4, 4)
+
+    def copy_poses_device(self, xi_ptr, T_ptr=0):
+        """Async D2D copy of the last poses into device memory (ints = device pointers, 0 = skip)."""
+        _check(lib().dvo_batch_copy_poses_device(self._p, C.c_void_p(xi_ptr or None), C.c_void_p(T_ptr or None)))
+
+    def last_track_log(self, seq):
+        log = TrackLog()
+        _check(lib().dvo_batch_last_track_log(self._p, seq, C.byref(log)))
+        return log.to_dict()
+
+    def synchronize(self):
+        _check(lib().dvo_batch_synchronize(self._p))
+
+    def profile(self, reset=False):
+        p = GnProfile()
+        _check(lib().dvo_batch_profile(self._p, C.byref(p), 1 if reset else 0))
+        return dict(gn_ms=p.gn_ms, gn_launches=p.gn_launches, gn_pixels=p.gn_pixels, gn_iterations=p.gn_iterations)
+
+    def probe_gn(self, level, n_launches):
+        ms = C.c_float(); px = C.c_uint64()
+        _check(lib().dvo_batch_probe_gn(self._p, level, n_launches, C.byref(ms), C.byref(px)))
+        return ms.value, px.value

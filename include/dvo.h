@@ -1,0 +1,198 @@
+/*
+ * dvo.h -- C ABI of libdvo.so: MI355X-native semi-dense direct visual odometry hot path.
+ *
+ * Drop-in boundary for the tracking/mapping path of KYabuuchi/direct-visual-odometry.  The reference has
+ * no FFI/plugin layer (plain C++ classes over cv::Mat), so each entry point below names the C++ interface
+ * it replaces (file:line under the reference tree).  All images are row-major contiguous float32, one
+ * channel; gray in [0,1]; DVO_INVALID (-2.0f) marks unusable pixels (include/math/util.hpp:7-10); depth
+ * and sigma in metres, depth 0 = none; K is a row-major 3x3; a twist xi is (vx,vy,vz,wx,wy,wz)
+ * (src/math/se3.cpp:74-75); poses are row-major 4x4.
+ *
+ * Ownership: the caller owns every buffer it passes; the library copies on entry and never keeps a host
+ * pointer.  `*_device` entry points take HIP device pointers (resident inputs, zero copy).
+ * Errors: every call returns a dvo_status; nothing aborts or throws (the reference abort()s or throws
+ * std::out_of_range: src/core/transform.cpp:16-17, include/system/frame.hpp:125).  Data sentinels are the
+ * reference's: residual -1 and a zero update when no pixel is valid (src/track/optimize.cpp:92-93).
+ * Threading: one handle = one HIP stream, used by one thread at a time; distinct handles are independent.
+ */
+#ifndef DVO_H
+#define DVO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVO_INVALID (-2.0f)
+#define DVO_MAX_LEVELS 8
+#define DVO_MAX_ITERATIONS 32
+
+typedef enum {
+    DVO_OK = 0,
+    DVO_ERR_BAD_ARGUMENT = 1,
+    DVO_ERR_HIP = 2,          /* a HIP runtime call failed; dvo_last_error() has the text            */
+    DVO_ERR_NO_DEVICE = 3,    /* no gfx950 device visible: the library has NO CPU fallback            */
+    DVO_ERR_NO_VALID_PIXELS = 4, /* informational: an optimize step had n_valid == 0                  */
+    DVO_ERR_NOT_READY = 5,    /* e.g. track requested before a reference frame exists                 */
+    DVO_ERR_OUT_OF_MEMORY = 6
+} dvo_status;
+
+/* Constants of the reference, runtime-configurable.  dvo_config_default() fills the reference's literals. */
+typedef struct dvo_config {
+    int      max_iterations;        /* 15    src/track/tracker.cpp:19                                   */
+    float    min_update;            /* 5e-4  src/track/tracker.cpp:17                                   */
+    float    min_residual;          /* 5e-3  src/track/tracker.cpp:16                                   */
+    int      fixed_iterations;      /* 0 = early exit as the reference; N>0 = exactly N per level       */
+    int      crop_enable;           /* 1 = level-2 crop of optimize.cpp:33-36 and mapper.cpp:90 crop    */
+    float    step_default;          /* 2.0   src/track/optimize.cpp:22                                  */
+    float    step_level1;           /* 1.5   src/track/optimize.cpp:23-24                               */
+    float    step_level2;           /* 1.0   src/track/optimize.cpp:25-26                               */
+    float    sigma_min, sigma_max;  /* 0.01, 0.5  src/track/optimize.cpp:83                             */
+    float    min_depth;             /* 0.20  src/track/optimize.cpp:39                                  */
+    float    keyframe_min_translation; /* 0.02 src/map/mapper.cpp:12                                    */
+    int      keyframe_max_frames;   /* 6     src/map/mapper.cpp:13                                      */
+    uint32_t rng_seed;              /* seed of the counter-based reset depth (replaces gaussian.cpp:8-9) */
+    int      device;                /* HIP device ordinal                                                */
+    void*    stream;                /* hipStream_t to launch on, or NULL for a library-owned stream      */
+    int      profile;               /* 1 = bracket every k_track_gn launch with hipEvents (bench only)   */
+    int      gn_pixels_per_thread;  /* 0 = choose from the problem size                                  */
+    int      gn_use_lds_patch;      /* -1 = auto, 0 = global gathers, 1 = LDS-staged reference patch     */
+} dvo_config;
+
+void        dvo_config_default(dvo_config* cfg);
+const char* dvo_version(void);
+const char* dvo_status_string(int status);
+const char* dvo_last_error(void);          /* thread-local text of the last failure */
+int         dvo_device_count(void);        /* number of visible HIP devices (0 = none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * System::VisualOdometry (include/system/system.hpp:12-104): frame in, pose out, one sequence.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dvo_vo dvo_vo;
+
+/* VisualOdometry(const cv::Mat1f& K), system.hpp:15.  width/height = size of the frames that will be fed. */
+int dvo_vo_create(const float K[9], int width, int height, const dvo_config* cfg, dvo_vo** out);
+int dvo_vo_destroy(dvo_vo* vo);
+/* Replaces the cv::randn initial depth of the first mono keyframe (include/system/frame.hpp:17-21):
+ * depth/sigma at the culled base resolution (width/4 x height/4).  Optional; default = hash-based
+ * N(1.5,0.5) clamped >= 0.5 with sigma 0.5. */
+int dvo_vo_set_initial_depth(dvo_vo* vo, const float* depth, const float* sigma);
+/* VisualOdometry(gray, depth, sigma, K), system.hpp:24-32: first keyframe with a given depth map. */
+int dvo_vo_init_keyframe(dvo_vo* vo, const float* gray, const float* depth, const float* sigma);
+/* cv::Mat1f odometrize(const cv::Mat1f& gray), system.hpp:44-74 -> 4x4 world pose exp(m_xi).
+ * is_keyframe (optional) receives 1 when the frame was promoted to keyframe. */
+int dvo_vo_odometrize(dvo_vo* vo, const float* gray, float T_world[16], int* is_keyframe);
+/* cv::Mat1f odometrizeUsingDepth(gray, depth, sigma), system.hpp:77-93 -> 4x4 RELATIVE pose. */
+int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, const float* sigma, float T_rel[16]);
+
+/* FrameHistory (include/system/frame.hpp:146-188): keyframe / depth-map access. index 0 = oldest. */
+int dvo_vo_keyframe_count(const dvo_vo* vo);
+int dvo_vo_keyframe_info(const dvo_vo* vo, int index, int* id, int* levels, int* top_width, int* top_height,
+                         float xi[6], float rel_xi[6]);
+/* Frame::gray/depth/sigma/age/K at a pyramid level (frame.hpp:125-139); any output pointer may be NULL.
+ * age is only stored for the top level. */
+int dvo_vo_keyframe_get(const dvo_vo* vo, int index, int level, float* gray, float* depth, float* sigma,
+                        float* age, float K[9]);
+/* the most recent non-keyframe frame's pose (Frame::m_xi, m_relative_xi) */
+int dvo_vo_last_frame_pose(const dvo_vo* vo, int* id, float xi[6], float rel_xi[6]);
+int dvo_vo_last_valid_updates(const dvo_vo* vo); /* "valid update: N pixel", src/map/mapper.cpp:136 */
+
+/* Per-iteration record the reference prints (src/track/tracker.cpp:56-61). */
+typedef struct dvo_track_log {
+    int   levels;
+    int   n_iter[DVO_MAX_LEVELS];
+    float residual[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS];
+    float update_norm[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS];
+    int   n_valid[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS];
+    float xi_after[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS][6];
+} dvo_track_log;
+int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched tracking: n_seq independent sequences on one GPU, frame-to-frame with sensor depth
+ * (the odometrizeUsingDepth loop of test/sequence.cpp:10-23, n_seq at a time).  Inputs are device
+ * pointers to [n_seq][height][width] float32 arrays already resident in HBM.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dvo_batch dvo_batch;
+
+int dvo_batch_create(int n_seq, const float K[9], int width, int height, int levels, int culls,
+                     const dvo_config* cfg, dvo_batch** out);
+int dvo_batch_destroy(dvo_batch* b);
+/* Frame(gray,depth,sigma,K,levels,culls) for every sequence (frame.hpp:91-106): builds the pyramids of the
+ * new frames, tracks them against the previous frames (Tracker::track, tracker.cpp:22-85) and makes them the
+ * new reference.  The first call only stores the reference.  Asynchronous on the handle's stream. */
+int dvo_batch_push_device(dvo_batch* b, const float* gray_dev, const float* depth_dev, const float* sigma_dev);
+/* same, from host memory (adds the H2D copies) */
+int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma);
+/* relative twists [n_seq][6] and 4x4 relative poses [n_seq][16] of the last push (synchronises). NULL = skip */
+int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel);
+/* asynchronous device-to-device copy of the last push's poses (on the handle's stream): pose-out without a
+ * host round trip.  xi_dst_dev [n_seq][6], T_dst_dev [n_seq][16]; either may be NULL. */
+int dvo_batch_copy_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev);
+int dvo_batch_last_track_log(dvo_batch* b, int seq, dvo_track_log* log);
+int dvo_batch_synchronize(dvo_batch* b);
+/* Profile counters (cfg.profile = 1): accumulated over every k_track_gn launch since the last reset. */
+typedef struct dvo_gn_profile {
+    double   gn_ms;             /* sum of hipEvent-bracketed k_track_gn durations                         */
+    uint64_t gn_launches;
+    uint64_t gn_pixels;         /* pixels evaluated (active sequences x level pixels), summed              */
+    uint64_t gn_iterations;     /* sequence-iterations executed                                            */
+} dvo_gn_profile;
+int dvo_batch_profile(dvo_batch* b, dvo_gn_profile* out, int reset);
+/* Roofline probe: launch k_track_gn `n_launches` times back to back on level `level` with every sequence
+ * active (poses unchanged, partials discarded) and return the average duration from two hipEvents. */
+int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, uint64_t* pixels_per_launch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level (host pointers): each runs the corresponding HIP kernel once.  Used by the parity
+ * tests and reusable on their own.  `dev` is the HIP device ordinal.
+ * ------------------------------------------------------------------------------------------------ */
+/* Convert::cullImage, src/core/convert.cpp:7-20.  dst is (w>>times) x (h>>times). */
+int dvo_op_cull_image(int dev, const float* src, int w, int h, int times, float* dst);
+/* Convert::gradiate, src/core/convert.cpp:41-75 */
+int dvo_op_gradient(int dev, const float* img, int w, int h, int xdir, float* out);
+/* Transform::warpImage, src/core/transform.cpp:35-51 */
+int dvo_op_warp_image(int dev, const float xi[6], const float* gray, const float* depth, int w, int h,
+                      const float K[9], float* out);
+/* Frame pyramid, src/system/frame.cpp:16-37: fills gray/depth/sigma level buffers (coarsest first, each
+ * (w>>culls>>(levels-1-i)) x (h>>culls>>(levels-1-i))), any of depth/sigma may be NULL. */
+int dvo_op_pyramid(int dev, const float* gray, const float* depth, const float* sigma, int w, int h,
+                   int levels, int culls, float* const gray_out[], float* const depth_out[], float* const sigma_out[]);
+/* Track::optimize, src/track/optimize.cpp:10-99: one Gauss-Newton step on one level.
+ * H = upper triangle of sum J^T J (21), g = sum J^T (w r) (6).  mask (optional, w*h bytes). */
+typedef struct dvo_gn_result {
+    double H[21];
+    double g[6];
+    double sum_r2;
+    int    n_valid;
+    float  xi_update[6];
+    float  residual;
+    float  xi_next[6];   /* se3::concatenate(xi, xi_update), tracker.cpp:46 */
+} dvo_gn_result;
+int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const float* ref_gray,
+                   const float* ref_depth, const float* ref_sigma, int w, int h, const float K[9],
+                   const float xi[6], int level, dvo_gn_result* out, uint8_t* mask);
+/* Tracker::track, src/track/tracker.cpp:22-85, on full-resolution frames (pyramids built on device). */
+int dvo_op_track(int dev, const dvo_config* cfg, const float* obj_gray, const float* ref_gray,
+                 const float* ref_depth, const float* ref_sigma, int w, int h, const float K[9],
+                 int levels, int culls, float xi_out[6], dvo_track_log* log);
+/* Map::Implement::propagate, src/map/implement.cpp:217-256 */
+int dvo_op_propagate(int dev, const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h,
+                     const float xi[6], const float K[9], float* depth, float* sigma, float* age);
+/* Map::Implement::regularize, src/map/implement.cpp:156-180 */
+int dvo_op_regularize(int dev, const float* depth, const float* sigma, int w, int h, float* out);
+/* Map::Mapper::update, src/map/mapper.cpp:76-137, against n_hist keyframes (oldest first, the last one is the
+ * reference keyframe whose depth/sigma/age are updated in place).  All maps are top-level w x h.
+ * hist_gray[i], hist_xi[i] (6 floats each) describe keyframe i. */
+int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float* const hist_gray[],
+                        const float* hist_xi, const float* obj_gray, const float obj_xi[6],
+                        const float obj_rel_xi[6], int obj_id, const float K[9], int w, int h,
+                        float* ref_depth, float* ref_sigma, float* ref_age, int* valid_updates);
+/* math::se3 (src/math/se3.cpp:70-131) evaluated ON THE DEVICE (the tracker's pose chain runs there) */
+int dvo_op_se3_exp(int dev, const float xi[6], float T[16]);
+int dvo_op_se3_log(int dev, const float T[16], float xi[6]);
+int dvo_op_se3_concatenate(int dev, const float a[6], const float b[6], float out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,339 @@
+"""GPU parity tests: the HIP path (through the C ABI of libdvo.so) against the CPU oracle on the same seeded
+inputs.  Bit-exact for masks / indices / per-pixel maps; stated float tolerances (tests/util.py) for reductions,
+solves and poses.  Run on the MI355X box with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+import dvo_amd as dvo
+import orc
+from util import K640, TOL_H_REL, TOL_POSE, TOL_UPD_ABS, TOL_UPD_REL, frames
+
+pytestmark = pytest.mark.gpu
+INV = np.float32(-2.0)
+
+
+def test_library_loads_and_sees_gpu():
+    assert dvo.device_count() >= 1
+    assert b"gfx950" in dvo.lib().dvo_version()
+
+
+# ---------------------------------------------------------------- math::se3 on the device
+def test_se3_device_matches_oracle():
+    rng = np.random.RandomState(0)
+    for scale in (1e-7, 1e-3, 0.05, 1.0):
+        for _ in range(8):
+            a = (rng.uniform(-1, 1, 6) * scale).astype(np.float32)
+            b = (rng.uniform(-1, 1, 6) * scale * 0.3).astype(np.float32)
+            np.testing.assert_allclose(dvo.se3.exp(a), orc.se3_exp(a), rtol=0, atol=1.2e-7)
+            T = orc.se3_exp(a)
+            np.testing.assert_allclose(dvo.se3.log(T), orc.se3_log(T), rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(dvo.se3.concatenate(a, b), orc.se3_concatenate(a, b), rtol=2e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------- Convert
+def test_cull_image_bit_exact():
+    rng = np.random.RandomState(1)
+    img = rng.uniform(0, 1, (97, 131)).astype(np.float32)
+    img[rng.uniform(size=img.shape) < 0.05] = INV
+    img[5, 7] = -7.0
+    img[8, 8] = np.nan
+    for t in (0, 1, 2, 3):
+        np.testing.assert_array_equal(dvo.Convert.cullImage(img, t), orc.cull_image(img, t))
+
+
+def test_gradiate_bit_exact():
+    rng = np.random.RandomState(2)
+    img = rng.uniform(0, 1, (60, 83)).astype(np.float32)
+    img[rng.uniform(size=img.shape) < 0.05] = INV
+    for xdir in (True, False):
+        np.testing.assert_array_equal(dvo.Convert.gradiate(img, xdir), orc.gradiate(img, xdir))
+    one = np.ones((1, 1), np.float32)  # degenerate sizes
+    np.testing.assert_array_equal(dvo.Convert.gradiate(one, True), orc.gradiate(one, True))
+
+
+def test_pyramid_matches_frame_construction():
+    g, d, s, _ = frames()
+    gg = g[0].copy(); dd = d[0].copy()
+    gg[100:110, 200:230] = INV
+    dd[50:60, 10:40] = 0.0
+    for levels, culls in ((4, 1), (3, 2), (5, 0)):
+        of = orc.OFrame(gg, dd, s[0], K640, levels, culls)
+        go, do, so = dvo.pyramid(gg, dd, s[0], levels, culls)
+        for l in range(levels):
+            np.testing.assert_array_equal(go[l], of.gray(l))
+            np.testing.assert_array_equal(do[l], of.depth(l))
+            np.testing.assert_array_equal(so[l], of.sigma(l))
+
+
+# ---------------------------------------------------------------- Transform::warpImage
+@pytest.mark.parametrize("level", [0, 2, 3])
+def test_warp_image_bit_exact(level):
+    g, d, s, _ = frames()
+    of = orc.OFrame(g[0], d[0], s[0], K640, 4, 1)
+    gray, depth, K = of.gray(level), of.depth(level), of.K(level)
+    depth[3:6, 4:9] = 0.0
+    gray[10:12, 10:14] = INV   # exercises the getSubpixel fill quirk
+    gray[20, 20:24] = 0.0      # black pixels: `last > 0` is false
+    xi = np.array([0.01, -0.006, 0.008, 0.004, -0.003, 0.006], np.float32)
+    got = dvo.Transform.warpImage(xi, gray, depth, K)
+    exp = orc.warp_image(xi, gray, depth, K)
+    np.testing.assert_array_equal(got, exp)
+
+
+# ---------------------------------------------------------------- Track::optimize
+def _gn_compare(obj_gray, ref_gray, ref_depth, ref_sigma, K, xi, level, cfg=None, crop=True):
+    o = orc.optimize(obj_gray, ref_gray, ref_depth, ref_sigma, K, xi, level, crop=crop, want_mask=True)
+    r = dvo.optimize(obj_gray, ref_gray, ref_depth, ref_sigma, K, xi, level, cfg=cfg, want_mask=True)
+    np.testing.assert_array_equal(r["mask"], o["mask"])          # pixel selection: bit exact
+    assert r["n_valid"] == o["n_valid"]
+    if o["n_valid"] == 0:
+        assert r["residual"] == np.float32(-1) and not r["xi_update"].any()
+        return o, r
+    hs = np.abs(o["H"]).max()
+    np.testing.assert_allclose(r["H"], o["H"], rtol=0, atol=TOL_H_REL * hs)
+    np.testing.assert_allclose(r["g"], o["g"], rtol=0, atol=TOL_H_REL * max(np.abs(o["g"]).max(), 1e-30))
+    np.testing.assert_allclose(r["sum_r2"], o["sum_r2"], rtol=2e-5)
+    np.testing.assert_allclose(r["residual"], o["residual"], rtol=2e-5)
+    un = np.linalg.norm(o["xi_update"])
+    np.testing.assert_allclose(r["xi_update"], o["xi_update"], rtol=0, atol=TOL_UPD_REL * un + TOL_UPD_ABS)
+    np.testing.assert_allclose(r["xi_next"], orc.se3_concatenate(xi, r["xi_update"]), rtol=2e-6, atol=1e-9)
+    return o, r
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_gn_step_parity_every_level(level):
+    g, d, s, _ = frames()
+    ref = orc.OFrame(g[0], d[0], s[0], K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], s[1], K640, 4, 1)
+    xi = np.array([0.002, -0.001, 0.003, 0.002, -0.001, 0.001], np.float32)
+    o, _ = _gn_compare(obj.gray(level), ref.gray(level), ref.depth(level), ref.sigma(level), ref.K(level), xi, level)
+    assert o["n_valid"] > 500
+
+
+def test_gn_step_invalid_pixels_borders_and_crop_off():
+    g, d, s, _ = frames()
+    ref = orc.OFrame(g[0], d[0], s[0], K640, 3, 2)
+    obj = orc.OFrame(g[2], d[2], s[2], K640, 3, 2)
+    rg, rd, rs, K = ref.gray(2), ref.depth(2), ref.sigma(2), ref.K(2)
+    og = obj.gray(2)
+    rng = np.random.RandomState(5)
+    rg[rng.uniform(size=rg.shape) < 0.03] = INV
+    og[rng.uniform(size=og.shape) < 0.03] = INV
+    rd[rng.uniform(size=rd.shape) < 0.05] = 0.0
+    rd[30:40, 50:60] = 0.15                      # below the 0.20 gate
+    rs[:, :80] = 0.003; rs[:, 80:] = 0.8          # both clamps of optimize.cpp:83
+    rg[60, 60:70] = 0.0
+    xi = np.array([0.03, -0.02, 0.01, 0.01, 0.02, -0.015], np.float32)  # large: many warps leave the image
+    _gn_compare(og, rg, rd, rs, K, xi, 2)
+    cfg = dvo.default_config(crop_enable=0)
+    _gn_compare(og, rg, rd, rs, K, xi, 2, cfg=cfg, crop=False)
+
+
+def test_gn_step_no_valid_pixels():
+    z = np.zeros((30, 40), np.float32)
+    K = np.array([[30, 0, 20], [0, 30, 15], [0, 0, 1]], np.float32)
+    _gn_compare(z + 0.5, z + 0.5, z, z + 0.5, K, np.zeros(6, np.float32), 0)
+
+
+def test_gn_step_is_bit_reproducible():
+    g, d, s, _ = frames()
+    ref = orc.OFrame(g[0], d[0], s[0], K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], s[1], K640, 4, 1)
+    xi = np.zeros(6, np.float32)
+    a = dvo.optimize(obj.gray(3), ref.gray(3), ref.depth(3), ref.sigma(3), ref.K(3), xi, 3)
+    b = dvo.optimize(obj.gray(3), ref.gray(3), ref.depth(3), ref.sigma(3), ref.K(3), xi, 3)
+    np.testing.assert_array_equal(a["H"], b["H"])
+    np.testing.assert_array_equal(a["g"], b["g"])
+    np.testing.assert_array_equal(a["xi_update"], b["xi_update"])
+
+
+# ---------------------------------------------------------------- Tracker::track
+def _track_compare(gi, gj, levels, culls, sigma_value, cfg=None):
+    g, d, s, _ = frames()
+    sg = np.full_like(d[gi], sigma_value)
+    ref = orc.OFrame(g[gi], d[gi], sg, K640, levels, culls)
+    obj = orc.OFrame(g[gj], d[gj], sg, K640, levels, culls)
+    xo, lo = orc.track(obj, ref)
+    xg, lg = dvo.track(g[gj], g[gi], d[gi], sg, K640, levels, culls, cfg=cfg)
+    return xo, lo, xg, lg
+
+
+@pytest.mark.parametrize("levels,culls", [(4, 1), (3, 2)])
+def test_track_parity_contracting_gain(levels, culls):
+    # sigma = 0.5 (what the mono pipeline starts from): gain <= 2, the iteration is stable
+    xo, lo, xg, lg = _track_compare(0, 1, levels, culls, 0.5)
+    assert lg["n_iter"] == lo["n_iter"]
+    for l in range(levels):
+        np.testing.assert_array_equal(lg["n_valid"][l], lo["n_valid"][l])
+        np.testing.assert_allclose(lg["residual"][l], lo["residual"][l], rtol=1e-4)
+        np.testing.assert_allclose(lg["xi_after"][l], lo["xi_after"][l], rtol=0, atol=TOL_POSE)
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=TOL_POSE)
+
+
+def test_track_over_relaxed_gain_per_iteration_parity():
+    # sigma = 0.1 (sensor depth, transform.cpp:75): w/2 = 10x over-relaxed, the reference's iteration is chaotic.
+    # Whole-call pose parity is meaningless there; what must hold is parity of EVERY iteration given its input pose.
+    g, d, s, _ = frames()
+    sg = np.full_like(d[0], 0.1)
+    ref = orc.OFrame(g[0], d[0], sg, K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], sg, K640, 4, 1)
+    xo, lo = orc.track(obj, ref)
+    xi = np.zeros(6, np.float32)
+    for l in range(4):
+        for it in range(lo["n_iter"][l]):
+            r = dvo.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l)
+            assert r["n_valid"] == lo["n_valid"][l][it]
+            np.testing.assert_allclose(r["residual"], lo["residual"][l][it], rtol=1e-4)
+            np.testing.assert_allclose(r["xi_next"], lo["xi_after"][l][it], rtol=0, atol=2e-4 * max(1.0, np.abs(xi).max() * 50))
+            xi = lo["xi_after"][l][it]  # follow the oracle's trajectory
+
+
+def test_track_fixed_iterations_roofline_preset():
+    g, d, s, _ = frames()
+    sg = np.full_like(d[0], 0.5)
+    cfg = dvo.default_config(fixed_iterations=3, crop_enable=0)
+    ref = orc.OFrame(g[0], d[0], sg, K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], sg, K640, 4, 1)
+    xo, lo = orc.track(obj, ref, crop=False, fixed_iters=3)
+    xg, lg = dvo.track(g[1], g[0], d[0], sg, K640, 4, 1, cfg=cfg)
+    assert lg["n_iter"] == [3, 3, 3, 3] == lo["n_iter"]
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
+
+
+# ---------------------------------------------------------------- Map::Implement
+def test_propagate_bit_exact():
+    g, d, s, _ = frames()
+    of = orc.OFrame(g[0], d[0], s[0], K640, 3, 2)
+    depth, sigma, K = of.depth(2), of.sigma(2), of.K(2)
+    rng = np.random.RandomState(3)
+    age = rng.randint(0, 5, depth.shape).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.1] = 0.0
+    for xi in ([0.01, -0.01, 0, 0, 0, 0],             # test/propagate.cpp:51
+               [0.05, 0.02, -0.3, 0.02, -0.03, 0.05],  # strong forward motion: many collisions
+               [0, 0, 0, 0, 0, 0]):
+        xi = np.array(xi, np.float32)
+        got = dvo.Implement.propagate(depth, sigma, age, xi, K)
+        exp = orc.propagate(depth, sigma, age, xi, K)
+        for a, b in zip(got, exp):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_regularize_bit_exact():
+    rng = np.random.RandomState(4)
+    # test/regularize.cpp:26-32: 50x50 randn(1.5,0.5) depth, randn(0.3,0.2) sigma, one spike
+    depth = rng.normal(1.5, 0.5, (50, 50)).astype(np.float32)
+    sigma = np.abs(rng.normal(0.3, 0.2, (50, 50))).astype(np.float32) + 0.01
+    depth[25, 25] = 3.0; sigma[25, 25] = 0.1
+    depth[0, 0] = 9.0
+    np.testing.assert_array_equal(dvo.Implement.regularize(depth, sigma), orc.regularize(depth, sigma))
+
+
+def _mapping_scene(n_frames=4, sigma0=0.5):
+    g, d, s, poses = frames(6, seed=7)
+    return g, d, s, poses
+
+
+def test_mapper_update_parity():
+    g, d, s, poses = frames(6, seed=7)
+    # two keyframes + one tracked frame, depth of the reference keyframe perturbed as in test/update.cpp:64-71
+    rng = np.random.RandomState(9)
+    kf0 = orc.OFrame(g[0], d[0], np.full_like(d[0], 0.5), K640, 3, 2, id=0)
+    kf1 = orc.OFrame(g[2], d[2], np.full_like(d[2], 0.5), K640, 3, 2, id=2)
+    obj = orc.OFrame(g[3], None, None, K640, 3, 2, id=3)
+    T01 = np.linalg.inv(poses[2]) @ poses[0]
+    T12 = np.linalg.inv(poses[3]) @ poses[2]
+    xi1 = orc.se3_log(T01.astype(np.float32)) * np.float32(20)   # exaggerate the baseline so stereo is informative
+    rel = orc.se3_log(T12.astype(np.float32)) * np.float32(20)
+    kf1.set_pose(xi1, xi1)
+    obj.set_pose(orc.se3_concatenate(xi1, rel), rel)
+    top_d = kf1.depth(2) + rng.normal(0, 0.05, kf1.depth(2).shape).astype(np.float32)
+    top_s = np.full_like(top_d, 0.3)
+    age = (rng.uniform(size=top_d.shape) < 0.5).astype(np.float32)   # half the pixels were born in kf0
+    kf1.update_depth_sigma(top_d, top_s)
+    kf1.set_age(age)
+    K = kf1.K(2)
+    got_d, got_s, got_a, got_v = dvo.mapper_update([kf0.gray(2), kf1.gray(2)], [kf0.xi, kf1.xi], obj.gray(2), obj.xi,
+                                                   obj.rel_xi, 3, K, top_d, top_s, age,
+                                                   cfg=dvo.default_config(rng_seed=11))
+    v = orc.mapper_update([kf0, kf1], obj, 11)
+    np.testing.assert_array_equal(got_a, kf1.age())
+    np.testing.assert_array_equal(got_d, kf1.depth(2))
+    np.testing.assert_array_equal(got_s, kf1.sigma(2))
+    assert got_v == v
+    assert (got_d != top_d).sum() > 100   # the test really exercised the update
+
+
+# ---------------------------------------------------------------- System::VisualOdometry
+def test_odometrize_using_depth_sequence():
+    g, d, s, _ = frames(4, sigma=0.5)
+    vo = dvo.VisualOdometry(K640, 640, 480)
+    ovo = orc.OVO(K640, 640, 480)
+    for i in range(4):
+        T = vo.odometrizeUsingDepth(g[i], d[i], s[i])
+        To = ovo.odometrize_depth(g[i], d[i], s[i])
+        np.testing.assert_allclose(T, To, rtol=0, atol=TOL_POSE)
+    vo.close()
+
+
+def test_odometrize_mono_mapping_sequence():
+    g, d, s, _ = frames(6, seed=7)
+    rng = np.random.RandomState(12)
+    d0 = orc.cull_image(d[0], 2)
+    init_d = (d0 + rng.normal(0, 0.1, d0.shape)).astype(np.float32)
+    init_s = np.full_like(init_d, 0.5)
+    vo = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(rng_seed=3))
+    ovo = orc.OVO(K640, 640, 480, seed=3)
+    vo.setInitialDepth(init_d, init_s)
+    ovo.set_initial_depth(init_d, init_s)
+    for i in range(6):
+        T, key = vo.odometrize(g[i])
+        To, keyo = ovo.odometrize(g[i])
+        assert key == keyo
+        np.testing.assert_allclose(T, To, rtol=0, atol=1e-4)
+        assert vo.keyframeCount() == ovo.keyframe_count()
+        kf = vo.keyframe(vo.keyframeCount() - 1)
+        okf = ovo.keyframe(ovo.keyframe_count() - 1)
+        np.testing.assert_array_equal(kf["age"], okf.age())
+        bad = np.abs(kf["depth"] - okf.depth(2)) > 1e-3
+        assert bad.mean() < 0.01   # pose differences of 1e-5 may flip a handful of stereo matches
+    vo.close()
+
+
+# ---------------------------------------------------------------- batch
+def test_batch_matches_single_and_is_deterministic():
+    g, d, s, _ = frames(4, sigma=0.5)
+    B = 3
+    perm = [[0, 1, 2], [1, 2, 3], [2, 1, 0]]  # sequence b sees frames perm[b]
+    xs = []
+    for rep in range(2):
+        bt = dvo.Batch(B, K640, 640, 480, 4, 1)
+        out = []
+        for step in range(3):
+            gg = np.stack([g[perm[b][step]] for b in range(B)])
+            dd = np.stack([d[perm[b][step]] for b in range(B)])
+            ss = np.stack([s[perm[b][step]] for b in range(B)])
+            bt.push_host(gg, dd, ss)
+            if step > 0:
+                out.append(bt.last_poses()[0].copy())
+        xs.append(np.stack(out))
+        bt.close()
+    np.testing.assert_array_equal(xs[0], xs[1])          # bit-reproducible
+    for b in range(B):
+        for step in (1, 2):
+            i, j = perm[b][step - 1], perm[b][step]
+            x1, _ = dvo.track(g[j], g[i], d[i], s[i], K640, 4, 1)
+            np.testing.assert_array_equal(xs[0][step - 1][b], x1)  # batching does not change a sequence's result
+
+
+def test_bad_arguments_return_status_not_abort():
+    L = dvo.lib()
+    assert L.dvo_vo_create(None, 640, 480, None, None) == 1
+    with pytest.raises(dvo.DvoError):
+        dvo.VisualOdometry(K640, 8, 8)
+    with pytest.raises(dvo.DvoError):
+        dvo.Batch(0, K640, 640, 480)
+    vo = dvo.VisualOdometry(K640, 640, 480)
+    with pytest.raises(dvo.DvoError):
+        vo.keyframeInfo(0)      # FrameHistory::operator[] .at() throws in the reference (frame.hpp:176)
+    vo.close()
