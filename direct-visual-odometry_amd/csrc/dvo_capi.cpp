@@ -318,7 +318,7 @@ int download(float* host, const void* dev, size_t count, hipStream_t s)
     DVO_HIP(hipMemcpyAsync(host, dev, count * sizeof(float), hipMemcpyDeviceToHost, s));
     return DVO_OK;
 }
-Intr intr_of(const float K[9]) { return Intr{K[0], K[4], K[2], K[5]}; }
+Intr intr_of(const float K[9]) { return make_intr(K); }
 }  // namespace
 
 int dvo_op_cull_image(int dev, const float* src, int w, int h, int times, float* dst)

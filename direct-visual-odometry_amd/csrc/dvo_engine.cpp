@@ -89,7 +89,7 @@ int make_geometry(const float K[9], int w, int h, int levels, int culls, Geometr
             return DVO_ERR_BAD_ARGUMENT;
         }
         cull_intrinsic(Kb, t, g.K9[i]);
-        g.k[i] = Intr{g.K9[i][0], g.K9[i][4], g.K9[i][2], g.K9[i][5]};
+        g.k[i] = make_intr(g.K9[i]);
         g.px_total += (size_t)g.w[i] * g.h[i];
     }
     return DVO_OK;

@@ -138,7 +138,7 @@ struct Acc29 {
 #pragma unroll
         for (int i = 0; i < 29; i++) a[i] = 0.0f;
     }
-    __device__ __forceinline__ void add(const float J[6], float r, float rw)
+    __device__ __forceinline__ void add(const float J[6], float r, float rw, float one)
     {
         int idx = 0;
 #pragma unroll
@@ -151,9 +151,50 @@ struct Acc29 {
 #pragma unroll
         for (int p = 0; p < 6; p++) a[21 + p] = fmaf(J[p], rw, a[21 + p]);
         a[27] = fmaf(r, r, a[27]);
-        a[28] += 1.0f;
+        a[28] += one;
     }
 };
+
+// dword-aligned wide loads (gfx950 global memory takes unaligned dwordx2/x4)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// the generic sampler as a real function: rare (border / INVALID taps), keeps the hot loop's code small
+__device__ __noinline__ bool gn_sample_slow(const float* img, int w, int h, float d, float u, float v, float* out3)
+{
+    const GlobalImg ref{img, w, h};
+    float I2, gx, gy;
+    const bool ok = gn_sample(ref, d, u, v, I2, gx, gy);
+    out3[0] = I2; out3[1] = gx; out3[2] = gy;
+    return ok;
+}
+
+// The 12 plus-shaped taps around (x0, y0) that warped gray (4 taps) and its central-difference gradient need.
+struct Taps {
+    f2u ra;  // row y0-1: cols x0, x0+1
+    f4u rb;  // row y0  : cols x0-1 .. x0+2
+    f4u rc;  // row y0+1: cols x0-1 .. x0+2
+    f2u rd;  // row y0+2: cols x0, x0+1
+};
+
+// Interior fast path.  When the 4x4 neighbourhood of the warped position lies inside the image and its 12 taps are
+// all valid, getSubpixel's fill loop is a no-op and Convert::gradiate has no border/invalid case, so warped gray
+// and gradient reduce to straight differences and three blend4() calls -- the SAME float operations the generic
+// path (dvo_math.h gn_sample) performs, without its per-tap branches.  Returns 1 = sampled, 0 = pixel rejected,
+// -1 = not decidable here (INVALID or NaN tap): take the generic path.
+__device__ __forceinline__ int gn_sample_fast(const Taps& t, float u, float v, int x0, int y0, float& I2, float& gx, float& gy)
+{  // branch free: everything is computed, the status is selected at the end
+    const float mn = fminf(fminf(fminf(t.ra.x, t.ra.y), fminf(t.rd.x, t.rd.y)),
+                           fminf(fminf(fminf(t.rb.x, t.rb.y), fminf(t.rb.z, t.rb.w)), fminf(fminf(t.rc.x, t.rc.y), fminf(t.rc.z, t.rc.w))));
+    const float hx = u - (float)x0, vy = v - (float)y0;
+    I2 = blend4(t.rb.y, t.rb.z, t.rc.y, t.rc.z, hx, vy);
+    gx = blend4(t.rb.z - t.rb.x, t.rb.w - t.rb.y, t.rc.z - t.rc.x, t.rc.w - t.rc.y, hx, vy);
+    gy = blend4(t.rc.y - t.ra.x, t.rc.z - t.ra.y, t.rd.x - t.rb.y, t.rd.y - t.rb.z, hx, vy);
+    const float probe = (I2 + gx) + gy;  // a NaN tap (fminf skips NaN) poisons at least one of the three
+    const bool decidable = (mn > kInvalid) && (probe == probe);
+    const bool valid = !(is_invalid(I2) || is_invalid(gx) || is_invalid(gy));
+    return decidable ? (valid ? 1 : 0) : -1;
+}
 
 template <int PPT>
 __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
@@ -168,31 +209,62 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
     const float* __restrict__ sig = a.ref_sigma + img_off;
-    const GlobalImg ref{a.ref_gray + img_off, a.w, a.h};
-    const int npix = a.w * a.h;
+    const float* __restrict__ refp = a.ref_gray + img_off;
+    const int w = a.w, h = a.h, npix = w * h;
     const int base = blk * (256 * PPT) + threadIdx.x;
+    const float wlim = (float)(w - 2), hlim = (float)(h - 2);
 
     Acc29 acc;
     acc.zero();
-    float d[PPT], I1[PPT], sg[PPT];
+    // G pixels per thread have their gathers in flight together (memory-level parallelism hides the L2/HBM latency)
+    constexpr int G = PPT < 4 ? PPT : 4;
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {  // issue the coalesced loads first
-        const int i = base + k * 256;
-        const bool in = i < npix;
-        d[k] = in ? dep[i] : 0.0f;
-        I1[k] = in ? obj[i] : kInvalid;
-        sg[k] = in ? sig[i] : 1.0f;
-    }
+    for (int g0 = 0; g0 < PPT; g0 += G) {
+        float d[G], I1[G], sg[G], u[G], v[G];
+        int xs[G], ys[G], x0[G], y0[G];
+        bool gate[G], inter[G];
+        Taps t[G];
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int i = base + k * 256;
-        if (i >= npix) continue;
-        int x, y;
-        split_index(i, a.w, a.inv_w, x, y);
-        float J[6], r, rw;
-        if (gn_pixel(ref, a.k, pose, a.prm, x, y, d[k], I1[k], sg[k], J, r, rw)) {
-            acc.add(J, r, rw);
-            if (a.mask) a.mask[img_off + i] = 1;
+        for (int k = 0; k < G; k++) {  // coalesced rows: ref_depth, obj_gray, ref_sigma
+            const int i = base + (g0 + k) * 256;
+            const bool in = i < npix;
+            d[k] = in ? dep[i] : 0.0f;
+            I1[k] = in ? obj[i] : kInvalid;
+            sg[k] = in ? sig[i] : 1.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
+            const int i = base + (g0 + k) * 256;
+            split_index(i < npix ? i : 0, w, a.inv_w, xs[k], ys[k]);
+            gate[k] = (i < npix) && gn_gate(a.prm, xs[k], ys[k], d[k], I1[k]);
+            warp(pose, a.k, (float)xs[k], (float)ys[k], d[k], u[k], v[k]);
+            inter[k] = gate[k] && u[k] >= 1.0f && v[k] >= 1.0f && u[k] < wlim && v[k] < hlim;  // false for NaN
+            x0[k] = inter[k] ? (int)u[k] : 1;
+            y0[k] = inter[k] ? (int)v[k] : 1;
+            const float* p = refp + (y0[k] * w + x0[k]);
+            t[k].ra = *reinterpret_cast<const f2u*>(p - w);
+            t[k].rb = *reinterpret_cast<const f4u*>(p - 1);
+            t[k].rc = *reinterpret_cast<const f4u*>(p + w - 1);
+            t[k].rd = *reinterpret_cast<const f2u*>(p + 2 * w);
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            float I2 = 0.0f, gx = 0.0f, gy = 0.0f;
+            int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2, gx, gy);
+            s = gate[k] ? (inter[k] ? s : -1) : 0;
+            if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
+                float o3[3];
+                s = gn_sample_slow(refp, w, h, d[k], u[k], v[k], o3) ? 1 : 0;
+                I2 = o3[0]; gx = o3[1]; gy = o3[2];
+            }
+            // predicated accumulation: rejected pixels add exact zeros, so no control flow merges the 29 accumulators
+            const bool ok = s > 0;
+            float J[6], r, rw;
+            gn_jacobian(a.k, a.prm, xs[k], ys[k], d[k], gx, gy, I1[k], I2, sg[k], J, r, rw);
+#pragma unroll
+            for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
+            acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
+            if (a.mask && ok) a.mask[img_off + base + (g0 + k) * 256] = 1;
         }
     }
     // wave reduction (DPP), then 4 waves through LDS in fixed order

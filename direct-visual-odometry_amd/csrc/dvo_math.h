@@ -21,7 +21,15 @@ constexpr float kEpsilon = 1e-6f;  // include/math/util.hpp:6
 
 struct Intr {  // fx, fy, cx, cy of a pyramid level (Convert::cullIntrinsic, src/core/convert.cpp:22-29)
     float fx, fy, cx, cy;
+    float ifx, ify;  // 1.0f / fx, 1.0f / fy: correctly rounded once per level
 };
+DVO_HD Intr make_intr(const float K[9])
+{
+    Intr k;
+    k.fx = K[0]; k.fy = K[4]; k.cx = K[2]; k.cy = K[5];
+    k.ifx = 1.0f / k.fx; k.ify = 1.0f / k.fy;
+    return k;
+}
 
 struct Pose {  // R (row major) and t of exp(+-xi), rounded to float once
     float R[9];
@@ -36,8 +44,10 @@ DVO_HD bool coord_ok(float v) { return fabsf(v) < 1073741824.0f; }  // D4: false
 // ---------------------------------------------------------------- geometry, src/core/transform.cpp:20-33
 DVO_HD void back_project(const Intr& k, float px, float py, float d, float& X, float& Y, float& Z)
 {
-    X = (d * (px - k.cx)) / k.fx;
-    Y = (d * (py - k.cy)) / k.fy;
+    // depth * (p - c) / f (transform.cpp:27): the division by the per-level constant f is a multiplication by its
+    // correctly rounded reciprocal -- the reference is built -Ofast (-freciprocal-math), see DESIGN.md §3 D8
+    X = (d * (px - k.cx)) * k.ifx;
+    Y = (d * (py - k.cy)) * k.ify;
     Z = d;
 }
 
@@ -50,8 +60,9 @@ DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float
 
 DVO_HD void project(const Intr& k, float X, float Y, float Z, float& u, float& v)
 {
-    u = (X * k.fx) / Z + k.cx;
-    v = (Y * k.fy) / Z + k.cy;
+    const float iz = 1.0f / Z;  // one correctly rounded reciprocal shared by both coordinates (D8)
+    u = (X * k.fx) * iz + k.cx;
+    v = (Y * k.fy) * iz + k.cy;
 }
 
 DVO_HD void warp(const Pose& p, const Intr& k, float px, float py, float d, float& u, float& v)
@@ -179,36 +190,57 @@ struct GnParams {
     int   crop;        // 1 when this level is cropped (optimize.cpp:33-36)
 };
 
-// Returns true when the pixel contributes; J[6], r (residual) and rw (weighted residual) are then set.
-template <class Img>
-DVO_HD bool gn_pixel(const Img& ref_gray, const Intr& k, const Pose& pose, const GnParams& prm, int x, int y,
-                     float d, float I1, float sigma, float J[6], float& r, float& rw)
+// Jacobian row, residual and weighted residual of one contributing pixel (optimize.cpp:67-89).
+DVO_HD void gn_jacobian(const Intr& k, const GnParams& prm, int x, int y, float d, float gx, float gy, float I1, float I2,
+                        float sigma, float J[6], float& r, float& rw)
 {
-    if (prm.crop && (x < 20 || x > 140 || y < 20 || y > 100)) return false;
-    if (d < prm.min_depth) return false;  // (double)d < 0.20  <=>  d < 0.2f for float d
-    float u, v;
-    warp(pose, k, (float)x, (float)y, d, u, v);
-    // warped_gray(x) = getSubpixel(ref_gray, warp(-xi, x, d)) (transform.cpp:35-51); d >= min_depth so never epsilon
-    const float I2 = is_epsilon(d) ? kInvalid : get_subpixel(ref_gray, u, v);
-    if (is_invalid(I1) || is_invalid(I2)) return false;
-    if (u < 0.0f || v < 0.0f || (float)ref_gray.w <= u || (float)ref_gray.h <= v) return false;
-    if (!coord_ok(u) || !coord_ok(v)) return false;  // D4 (NaN passes the comparisons above)
-    float gx, gy;
-    grad_subpixel(ref_gray, u, v, gx, gy);
-    if (is_invalid(gx) || is_invalid(gy)) return false;
     float X, Y, Z;
     back_project(k, (float)x, (float)y, d, X, Y, Z);
     const float fgx = k.fx * gx, fgy = k.fy * gy;
-    const float xz = X / Z, yz = Y / Z;
-    J[0] = fgx / Z;
-    J[1] = fgy / Z;
-    J[2] = ((-fmaf(fgy, Y, fgx * X)) / Z) / Z;
+    const float iz = 1.0f / Z;  // the six divisions by z of optimize.cpp:70-74 share one reciprocal (D8)
+    const float xz = X * iz, yz = Y * iz;
+    J[0] = fgx * iz;
+    J[1] = fgy * iz;
+    J[2] = ((-fmaf(fgy, Y, fgx * X)) * iz) * iz;
     J[3] = -(((fgx * xz) * yz) + (fgy * fmaf(yz, yz, 1.0f)));
     J[4] = (fgx * fmaf(xz, xz, 1.0f)) + ((fgy * xz) * yz);
     J[5] = fmaf(fgy, xz, -(fgx * yz));
     r = I2 - I1;
     const float sc = sigma < prm.sigma_min ? prm.sigma_min : (prm.sigma_max < sigma ? prm.sigma_max : sigma);
     rw = r * (prm.step / sc);
+}
+
+// The gates of optimize.cpp:33-48 that do not need the warp.  (double)d < 0.20  <=>  d < 0.2f for float d.
+DVO_HD bool gn_gate(const GnParams& prm, int x, int y, float d, float I1)
+{
+    if (prm.crop && (x < 20 || x > 140 || y < 20 || y > 100)) return false;
+    if (d < prm.min_depth) return false;
+    return !is_invalid(I1);
+}
+
+// Generic sampling part (any position, any validity pattern): warped gray I2 and the gradient at (u, v).
+template <class Img>
+DVO_HD bool gn_sample(const Img& ref_gray, float d, float u, float v, float& I2, float& gx, float& gy)
+{
+    // warped_gray(x) = getSubpixel(ref_gray, warp(-xi, x, d)) (transform.cpp:35-51)
+    I2 = is_epsilon(d) ? kInvalid : get_subpixel(ref_gray, u, v);
+    if (is_invalid(I2)) return false;
+    if (u < 0.0f || v < 0.0f || (float)ref_gray.w <= u || (float)ref_gray.h <= v) return false;
+    if (!coord_ok(u) || !coord_ok(v)) return false;  // D4 (NaN passes the comparisons above)
+    grad_subpixel(ref_gray, u, v, gx, gy);
+    return !(is_invalid(gx) || is_invalid(gy));
+}
+
+// Returns true when the pixel contributes; J[6], r (residual) and rw (weighted residual) are then set.
+template <class Img>
+DVO_HD bool gn_pixel(const Img& ref_gray, const Intr& k, const Pose& pose, const GnParams& prm, int x, int y,
+                     float d, float I1, float sigma, float J[6], float& r, float& rw)
+{
+    if (!gn_gate(prm, x, y, d, I1)) return false;
+    float u, v, I2, gx, gy;
+    warp(pose, k, (float)x, (float)y, d, u, v);
+    if (!gn_sample(ref_gray, d, u, v, I2, gx, gy)) return false;
+    gn_jacobian(k, prm, x, y, d, gx, gy, I1, I2, sigma, J, r, rw);
     return true;
 }
 

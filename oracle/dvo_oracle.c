@@ -351,16 +351,19 @@ float orc_get_subpixel(const float* img, int w, int h, float px, float py)
 /* Geometry.  src/core/transform.cpp                                         */
 /* ======================================================================== */
 void orc_back_project(const float K[9], float px, float py, float d, float X[3])
-{ /* transform.cpp:25-28: depth * (p - c) / f, left to right */
-    X[0] = (d * (px - K[2])) / K[0];
-    X[1] = (d * (py - K[5])) / K[4];
+{ /* transform.cpp:25-28: depth * (p - c) / f.  D8: the division by the per-level constant f is a multiplication
+   * by its correctly rounded reciprocal (the reference is built -Ofast, i.e. -freciprocal-math) */
+    const float ifx = 1.0f / K[0], ify = 1.0f / K[4];
+    X[0] = (d * (px - K[2])) * ifx;
+    X[1] = (d * (py - K[5])) * ify;
     X[2] = d;
 }
 
 void orc_project(const float K[9], const float X[3], float p[2])
-{ /* transform.cpp:20-23 */
-    p[0] = (X[0] * K[0]) / X[2] + K[2];
-    p[1] = (X[1] * K[4]) / X[2] + K[5];
+{ /* transform.cpp:20-23; D8: one reciprocal of z shared by both coordinates */
+    const float iz = 1.0f / X[2];
+    p[0] = (X[0] * K[0]) * iz + K[2];
+    p[1] = (X[1] * K[4]) * iz + K[5];
 }
 
 void orc_transform(const float Rt[12], const float X[3], float Y[3])
@@ -592,10 +595,11 @@ static int optimize_pixel(const float* obj_gray, const float* gradx, const float
     const float fx = K[0], fy = K[4];
     const float xx = X[0], yy = X[1], zz = X[2];
     const float fgx = fx * gx, fgy = fy * gy;
-    const float xz = xx / zz, yz = yy / zz;
-    J[0] = fgx / zz;
-    J[1] = fgy / zz;
-    J[2] = ((-fmaf(fgy, yy, fgx * xx)) / zz) / zz;
+    const float iz = 1.0f / zz; /* D8: the six divisions by z of optimize.cpp:70-74 share one reciprocal */
+    const float xz = xx * iz, yz = yy * iz;
+    J[0] = fgx * iz;
+    J[1] = fgy * iz;
+    J[2] = ((-fmaf(fgy, yy, fgx * xx)) * iz) * iz;
     J[3] = -(((fgx * xz) * yz) + (fgy * fmaf(yz, yz, 1.0f)));
     J[4] = (fgx * fmaf(xz, xz, 1.0f)) + ((fgy * xz) * yz);
     J[5] = fmaf(fgy, xz, -(fgx * yz));
