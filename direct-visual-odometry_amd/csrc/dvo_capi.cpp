@@ -36,6 +36,7 @@ void dvo_config_default(dvo_config* c)
     c->profile = 0;
     c->gn_pixels_per_thread = 0;
     c->gn_use_lds_patch = -1;
+    c->gn_gather_group = 0;
 }
 
 const char* dvo_version(void) { return "dvo-mi355x 0.1 (gfx950)"; }
@@ -281,9 +282,9 @@ int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, u
     hipEvent_t e0, e1;
     DVO_HIP(hipEventCreate(&e0));
     DVO_HIP(hipEventCreate(&e1));
-    launch_track_gn(ga, B.n_seq, B.trk.ppt[level], B.stream);  // warm
+    B.trk.launch_gn(ga, level, B.stream);  // warm
     DVO_HIP(hipEventRecord(e0, B.stream));
-    for (int i = 0; i < n_launches; i++) launch_track_gn(ga, B.n_seq, B.trk.ppt[level], B.stream);
+    for (int i = 0; i < n_launches; i++) B.trk.launch_gn(ga, level, B.stream);
     DVO_HIP(hipEventRecord(e1, B.stream));
     DVO_HIP(hipEventSynchronize(e1));
     float ms = 0;
@@ -388,7 +389,9 @@ int dvo_op_pyramid(int dev, const float* gray, const float* depth, const float* 
     Geometry g;
     DVO_TRY(make_geometry(Kid, w, h, levels, culls, g));
     FrameSet fs;
-    DVO_TRY(fs.alloc(g, 1));
+    dvo_config dc;
+    dvo_config_default(&dc);
+    DVO_TRY(fs.alloc(g, 1, dc));
     const size_t n = (size_t)w * h;
     DevBuf a, b, s3;
     DVO_TRY(upload(a, gray, n, c.s));
@@ -434,7 +437,22 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     if (mask) { DVO_TRY(mk.alloc(n)); DVO_HIP(hipMemsetAsync(mk.p, 0, n, c.s)); }
     launch_set_pose(trk.state.as<SeqState>(), xin.as<float>(), 1, c.s);
     GnArgs ga;
-    ga.obj_gray = og.as<float>(); ga.ref_gray = rg.as<float>(); ga.ref_depth = rd.as<float>(); ga.ref_sigma = rs.as<float>();
+    // per-pixel constants of the reference level (what build_pyramid does for whole frames)
+    DevBuf izb, wgb;
+    DVO_TRY(izb.alloc(n * 4));
+    DVO_TRY(wgb.alloc(n * 4));
+    {
+        PrepArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.depth = rd.as<float>(); pa.sigma = rs.as<float>(); pa.iz = izb.as<float>(); pa.wgt = wgb.as<float>();
+        pa.level_end[0] = n;
+        pa.step[0] = trk.level_params(level).step;
+        pa.sigma_min = cf.sigma_min; pa.sigma_max = cf.sigma_max;
+        pa.levels = 1;
+        launch_prep_ref(pa, c.s);
+    }
+    ga.obj_gray = og.as<float>(); ga.ref_gray = rg.as<float>(); ga.ref_depth = rd.as<float>();
+    ga.ref_iz = izb.as<float>(); ga.ref_wgt = wgb.as<float>();
     ga.state = trk.state.as<SeqState>();
     ga.partials = trk.partials.as<float>();
     ga.mask = mask ? mk.as<uint8_t>() : nullptr;
@@ -442,7 +460,8 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     ga.k = gl.k[level];
     ga.prm = trk.level_params(level);
     ga.ignore_active = 1;
-    launch_track_gn(ga, 1, trk.ppt[level], c.s);
+    ga.tiles_x = trk.tiles_x[level]; ga.tiles_y = trk.tiles_y[level]; ga.margin = trk.tile_margin;
+    trk.launch_gn(ga, level, c.s);
     SolveArgs sa;
     sa.state = trk.state.as<SeqState>(); sa.partials = trk.partials.as<float>();
     sa.log = nullptr; sa.result = res.as<dvo_gn_result>(); sa.counters = nullptr;
@@ -467,8 +486,8 @@ int dvo_op_track(int dev, const dvo_config* cfg, const float* obj_gray, const fl
     Geometry g;
     DVO_TRY(make_geometry(K, w, h, levels, culls, g));
     FrameSet obj, ref;
-    DVO_TRY(obj.alloc(g, 1));
-    DVO_TRY(ref.alloc(g, 1));
+    DVO_TRY(obj.alloc(g, 1, cf));
+    DVO_TRY(ref.alloc(g, 1, cf));
     Tracker trk;
     DVO_TRY(trk.init(g, 1, cf));
     const size_t n = (size_t)w * h;

@@ -95,18 +95,45 @@ int make_geometry(const float K[9], int w, int h, int levels, int culls, Geometr
     return DVO_OK;
 }
 
-int FrameSet::alloc(const Geometry& geo, int n)
+static float level_step(const dvo_config& c, int level)
+{  // optimize.cpp:22-26
+    if (level == 1) return c.step_level1;
+    if (level == 2) return c.step_level2;
+    return c.step_default;
+}
+
+int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
 {
     g = geo;
     n_seq = n;
-    DVO_TRY(arena.alloc(3 * g.px_total * (size_t)n * sizeof(float)));
+    DVO_TRY(arena.alloc(5 * g.px_total * (size_t)n * sizeof(float)));
     float* p = arena.as<float>();
-    for (int m = 0; m < 3; m++)
+    for (int m = 0; m < 5; m++)
         for (int l = 0; l < g.levels; l++) {
-            (m == 0 ? gray : m == 1 ? depth : sigma)[l] = p;
+            (m == 0 ? gray : m == 1 ? depth : m == 2 ? sigma : m == 3 ? iz : wgt)[l] = p;
             p += (size_t)g.w[l] * g.h[l] * n;
         }
+    for (int l = 0; l < g.levels; l++) step[l] = level_step(cfg, l);
+    sigma_min = cfg.sigma_min;
+    sigma_max = cfg.sigma_max;
     return DVO_OK;
+}
+
+// iz / wgt of every level from the current depth / sigma pyramids (k_prep_ref)
+static void prep_reference(FrameSet& fs, hipStream_t s)
+{
+    PrepArgs a;
+    memset(&a, 0, sizeof a);
+    a.depth = fs.depth[0]; a.sigma = fs.sigma[0]; a.iz = fs.iz[0]; a.wgt = fs.wgt[0];  // levels are contiguous
+    size_t end = 0;
+    for (int l = 0; l < fs.g.levels; l++) {
+        end += (size_t)fs.g.w[l] * fs.g.h[l] * fs.n_seq;
+        a.level_end[l] = end;
+        a.step[l] = fs.step[l];
+    }
+    a.sigma_min = fs.sigma_min; a.sigma_max = fs.sigma_max;
+    a.levels = fs.g.levels;
+    launch_prep_ref(a, s);
 }
 
 void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s)
@@ -121,6 +148,7 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
     }
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
     launch_pyramid(a, fs.n_seq, s);
+    if (depth_dev && sigma_dev) prep_reference(fs, s);
 }
 
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s)
@@ -136,6 +164,7 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
     }
     a.inv_tw = 1.0f / (float)fs.g.w[T];
     launch_pyramid(a, fs.n_seq, s);
+    prep_reference(fs, s);
 }
 
 // ------------------------------------------------------------------------------------------------ tracker
@@ -155,14 +184,31 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         return DVO_ERR_BAD_ARGUMENT;
     }
     size_t max_part = 0;
+    // gn_use_lds_patch: -1 = auto, 0 = global gathers, N > 0 = LDS patch with margin N.  Auto is the global-gather
+    // kernel: measured on MI355X (profiles/r01_gn_variants.md) the LDS-staged variant is 10-15 % slower.
+    tile_margin = cfg.gn_use_lds_patch < 0 ? 0 : cfg.gn_use_lds_patch;
+    if (tile_margin > 24) tile_margin = 24;
     for (int l = 0; l < g.levels; l++) {
         int p = cfg.gn_pixels_per_thread;
-        if (p != 1 && p != 2 && p != 4 && p != 8) {  // auto: biggest tile that still gives >= 4 workgroups per CU
-            p = 8;
-            while (p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
+        const bool auto_p = (p != 1 && p != 2 && p != 4 && p != 8);
+        if (auto_p) p = 4;  // auto: biggest tile that still gives >= 4 workgroups per CU
+        if (tile_margin > 0) {
+            gn_tile_geometry(g.w[l], g.h[l], p, tiles_x[l], tiles_y[l]);
+            while (auto_p && p > 1 && (size_t)n_seq * tiles_x[l] * tiles_y[l] < 1024) {
+                p >>= 1;
+                gn_tile_geometry(g.w[l], g.h[l], p, tiles_x[l], tiles_y[l]);
+            }
+            nblk[l] = tiles_x[l] * tiles_y[l];
+        } else {
+            while (auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
+            nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p);
+            tiles_x[l] = tiles_y[l] = 0;
         }
         ppt[l] = p;
-        nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p);
+        int gg = cfg.gn_gather_group;
+        if (gg != 1 && gg != 2 && gg != 4) gg = 2;
+        while (gg > p || p % gg) gg >>= 1;
+        group[l] = gg < 1 ? 1 : gg;
         if ((size_t)nblk[l] > max_part) max_part = nblk[l];
     }
     DVO_TRY(state.alloc(sizeof(SeqState) * (size_t)n_seq));
@@ -194,7 +240,8 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     a.obj_gray = obj.gray[level];
     a.ref_gray = ref.gray[level];
     a.ref_depth = ref.depth[level];
-    a.ref_sigma = ref.sigma[level];
+    a.ref_iz = ref.iz[level];
+    a.ref_wgt = ref.wgt[level];
     a.state = state.as<SeqState>();
     a.partials = partials.as<float>();
     a.mask = mask;
@@ -203,7 +250,14 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     a.k = g.k[level];
     a.prm = level_params(level);
     a.ignore_active = ignore_active;
+    a.tiles_x = tiles_x[level]; a.tiles_y = tiles_y[level]; a.margin = tile_margin;
     return a;
+}
+
+void Tracker::launch_gn(const GnArgs& a, int level, hipStream_t s) const
+{
+    if (tile_margin > 0) launch_track_gn_tile(a, n_seq, ppt[level], s);
+    else launch_track_gn(a, n_seq, ppt[level], group[level], s);
 }
 
 int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
@@ -227,11 +281,11 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                     ev_pool.emplace_back(e0, e1);
                 }
                 DVO_HIP(hipEventRecord(ev_pool[ev_used].first, s));
-                launch_track_gn(ga, n_seq, ppt[level], s);
+                launch_gn(ga, level, s);
                 DVO_HIP(hipEventRecord(ev_pool[ev_used].second, s));
                 ev_used++;
             } else {
-                launch_track_gn(ga, n_seq, ppt[level], s);
+                launch_gn(ga, level, s);
             }
             SolveArgs sa;
             sa.state = state.as<SeqState>();
@@ -272,9 +326,9 @@ int Tracker::collect_profile(hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------ keyframes
-int Keyframe::alloc(const Geometry& g)
+int Keyframe::alloc(const Geometry& g, const dvo_config& cfg)
 {
-    DVO_TRY(fs.alloc(g, 1));
+    DVO_TRY(fs.alloc(g, 1, cfg));
     DVO_TRY(age.alloc(sizeof(float) * (size_t)g.w[g.top()] * g.h[g.top()]));
     return DVO_OK;
 }
@@ -330,7 +384,7 @@ int VisualOdometry::init_keyframe(const float* gray, const float* depth, const f
     DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
     auto kf = std::make_unique<Keyframe>();
-    DVO_TRY(kf->alloc(geoM));
+    DVO_TRY(kf->alloc(geoM, cfg));
     kf->id = ++latest_id;
     build_pyramid(kf->fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
     DVO_HIP(hipMemsetAsync(kf->age.p, 0, kf->age.bytes, stream));
@@ -400,7 +454,7 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     DVO_TRY(select_device(device));
     if (!trkM_ready) { DVO_TRY(trkM.init(geoM, 1, cfg)); trkM_ready = true; }
     DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
-    if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM)); }
+    if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg)); }
     Keyframe& frame = *scratch;
     frame.id = ++latest_id;
     for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
@@ -458,7 +512,7 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
     DVO_HIP(hipMemcpyAsync(in_gray.p, gray, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
-    if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD)); }
+    if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
     Keyframe& frame = *depth_cur;
     frame.id = ++latest_id;
     build_pyramid(frame.fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
@@ -501,8 +555,8 @@ int Batch::init(int n, const float K9[9], int w, int h, int levels, int culls, c
     if (cfg.stream) stream = (hipStream_t)cfg.stream;
     else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
     DVO_TRY(make_geometry(K9, w, h, levels, culls, g));
-    DVO_TRY(fs[0].alloc(g, n));
-    DVO_TRY(fs[1].alloc(g, n));
+    DVO_TRY(fs[0].alloc(g, n, cfg));
+    DVO_TRY(fs[1].alloc(g, n, cfg));
     DVO_TRY(trk.init(g, n, cfg));
     return DVO_OK;
 }

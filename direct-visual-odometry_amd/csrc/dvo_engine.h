@@ -59,7 +59,14 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
     float* gray[DVO_MAX_LEVELS] = {nullptr};
     float* depth[DVO_MAX_LEVELS] = {nullptr};
     float* sigma[DVO_MAX_LEVELS] = {nullptr};
-    int alloc(const Geometry& geo, int n);
+    // Per-pixel constants of a REFERENCE frame, derived once per frame instead of once per GN iteration:
+    // iz = 1.0f / depth and wgt = step(level) / clamp(sigma) (optimize.cpp:70-74,83-84).  Same float operations,
+    // hoisted out of the iteration loop.
+    float* iz[DVO_MAX_LEVELS] = {nullptr};
+    float* wgt[DVO_MAX_LEVELS] = {nullptr};
+    float step[DVO_MAX_LEVELS] = {0};
+    float sigma_min = 0.01f, sigma_max = 0.5f;
+    int alloc(const Geometry& geo, int n, const dvo_config& cfg);
 };
 
 // Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
@@ -72,7 +79,10 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int n_seq = 0;
     dvo_config cfg;
     DevBuf state, partials, log, counters, xi_out, T_out;
-    int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS];
+    int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
+    int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
+    int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
+    void launch_gn(const GnArgs& a, int level, hipStream_t s) const;
     // profiling (cfg.profile)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -92,7 +102,7 @@ struct Keyframe {  // System::Frame of one sequence, plus the age map and pose (
     DevBuf age;    // top-level [h][w]
     float xi[6] = {0, 0, 0, 0, 0, 0}, rel_xi[6] = {0, 0, 0, 0, 0, 0};
     int id = -1, ref_id = -1;
-    int alloc(const Geometry& g);
+    int alloc(const Geometry& g, const dvo_config& cfg);
 };
 
 struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104

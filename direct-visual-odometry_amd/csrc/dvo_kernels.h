@@ -28,7 +28,8 @@ struct GnArgs {
     const float* obj_gray;   // level buffers [n_seq][h][w]
     const float* ref_gray;
     const float* ref_depth;
-    const float* ref_sigma;
+    const float* ref_iz;     // 1.0f / ref_depth            (k_prep_ref)
+    const float* ref_wgt;    // step / clamp(ref_sigma)     (k_prep_ref)
     const SeqState* state;
     float* partials;         // [n_seq][nblk][32]
     uint8_t* mask;           // optional [n_seq][h][w], pre-zeroed
@@ -37,6 +38,20 @@ struct GnArgs {
     Intr k;
     GnParams prm;
     int ignore_active;       // 1 on the first iteration of a level / probes
+    // k_track_gn_tile only: 64 x (4*PPT) pixel tiles with the reference patch staged in LDS
+    int tiles_x, tiles_y;    // nblk = tiles_x * tiles_y
+    int margin;              // patch = tile grown by margin+1 (left/top) and margin+2 (right/bottom) pixels
+};
+
+struct PrepArgs {  // per-pixel constants of a reference frame, all levels in one launch
+    const float* depth;      // level buffers are contiguous: [level][n_seq][h][w]
+    const float* sigma;
+    float* iz;
+    float* wgt;
+    size_t level_end[DVO_MAX_LEVELS];  // cumulative element count after each level
+    float step[DVO_MAX_LEVELS];
+    float sigma_min, sigma_max;
+    int levels;
 };
 
 struct SolveArgs {
@@ -75,7 +90,15 @@ void launch_cull(const float* src, int w, int h, int times, float* dst, hipStrea
 void launch_gradient(const float* img, int w, int h, int xdir, float* out, hipStream_t s);
 void launch_warp_image(const float* gray, const float* depth, int w, int h, const Intr& k, const Pose& pose, float* out, hipStream_t s);
 int  gn_blocks_per_seq(int w, int h, int ppt);
-void launch_track_gn(const GnArgs& a, int n_seq, int ppt, hipStream_t s);
+void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s);
+void launch_prep_ref(const PrepArgs& a, hipStream_t s);
+// LDS-tiled variant: a.tiles_x/tiles_y/margin/nblk must be set (see gn_tile_geometry)
+void launch_track_gn_tile(const GnArgs& a, int n_seq, int ppt, hipStream_t s);
+inline void gn_tile_geometry(int w, int h, int ppt, int& tiles_x, int& tiles_y)
+{
+    tiles_x = (w + 63) / 64;
+    tiles_y = (h + 4 * ppt - 1) / (4 * ppt);
+}
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s);
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s);
 void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_t s);

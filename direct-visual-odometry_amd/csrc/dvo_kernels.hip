@@ -44,11 +44,12 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 }
 
 __device__ __forceinline__ void split_index(int i, int w, float inv_w, int& x, int& y)
-{  // i < 2^24: y = i / w without an integer divide
+{  // i < 2^24: y = i / w without an integer divide; the +-1 fix-up is branch free
     y = (int)((float)i * inv_w);
     x = i - y * w;
-    if (x < 0) { y -= 1; x += w; }
-    else if (x >= w) { y += 1; x -= w; }
+    const int lo = x < 0 ? 1 : 0, hi = x >= w ? 1 : 0;
+    y += hi - lo;
+    x += (lo - hi) * w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,10 +183,19 @@ struct Taps {
 // and gradient reduce to straight differences and three blend4() calls -- the SAME float operations the generic
 // path (dvo_math.h gn_sample) performs, without its per-tap branches.  Returns 1 = sampled, 0 = pixel rejected,
 // -1 = not decidable here (INVALID or NaN tap): take the generic path.
+// v_min3_f32 without the canonicalising v_max that fminf() adds to every loaded operand.  NaN operands are either
+// skipped (caught by the probe below) or returned (fails the > test): both end in the generic path.
+__device__ __forceinline__ float min3_raw(float a, float b, float c)
+{
+    float m;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
+
 __device__ __forceinline__ int gn_sample_fast(const Taps& t, float u, float v, int x0, int y0, float& I2, float& gx, float& gy)
 {  // branch free: everything is computed, the status is selected at the end
-    const float mn = fminf(fminf(fminf(t.ra.x, t.ra.y), fminf(t.rd.x, t.rd.y)),
-                           fminf(fminf(fminf(t.rb.x, t.rb.y), fminf(t.rb.z, t.rb.w)), fminf(fminf(t.rc.x, t.rc.y), fminf(t.rc.z, t.rc.w))));
+    const float mn = min3_raw(min3_raw(min3_raw(t.ra.x, t.ra.y, t.rd.x), min3_raw(t.rb.x, t.rb.y, t.rb.z), min3_raw(t.rc.x, t.rc.y, t.rc.z)),
+                              min3_raw(t.rd.y, t.rb.w, t.rc.w), t.rd.y);
     const float hx = u - (float)x0, vy = v - (float)y0;
     I2 = blend4(t.rb.y, t.rb.z, t.rc.y, t.rc.z, hx, vy);
     gx = blend4(t.rb.z - t.rb.x, t.rb.w - t.rb.y, t.rc.z - t.rc.x, t.rc.w - t.rc.y, hx, vy);
@@ -196,7 +206,22 @@ __device__ __forceinline__ int gn_sample_fast(const Taps& t, float u, float v, i
     return decidable ? (valid ? 1 : 0) : -1;
 }
 
-template <int PPT>
+// k_prep_ref: per-pixel constants of a reference frame (all levels, one launch): iz = 1/depth and
+// wgt = step(level) / clamp(sigma) -- the two per-pixel divisions of optimize.cpp:70-74,83-84 that do not depend on
+// the pose, evaluated once per frame instead of once per Gauss-Newton iteration.
+__global__ void __launch_bounds__(256) k_prep_ref(PrepArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.level_end[a.levels - 1]) return;
+    float step = a.step[0];
+#pragma unroll
+    for (int l = 1; l < DVO_MAX_LEVELS; l++)
+        if (l < a.levels && i >= a.level_end[l - 1]) step = a.step[l];
+    a.iz[i] = 1.0f / a.depth[i];
+    a.wgt[i] = gn_weight(step, a.sigma_min, a.sigma_max, a.sigma[i]);
+}
+
+template <int PPT, int G, bool MASK>
 __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
 {
     __shared__ float red[4][32];
@@ -208,7 +233,8 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
-    const float* __restrict__ sig = a.ref_sigma + img_off;
+    const float* __restrict__ izp = a.ref_iz + img_off;
+    const float* __restrict__ wgp = a.ref_wgt + img_off;
     const float* __restrict__ refp = a.ref_gray + img_off;
     const int w = a.w, h = a.h, npix = w * h;
     const int base = blk * (256 * PPT) + threadIdx.x;
@@ -217,28 +243,31 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     Acc29 acc;
     acc.zero();
     // G pixels per thread have their gathers in flight together (memory-level parallelism hides the L2/HBM latency)
-    constexpr int G = PPT < 4 ? PPT : 4;
+    static_assert(PPT % G == 0, "PPT must be a multiple of G");
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
-        float d[G], I1[G], sg[G], u[G], v[G];
+        float d[G], I1[G], iz[G], wg[G], u[G], v[G];
         int xs[G], ys[G], x0[G], y0[G];
         bool gate[G], inter[G];
         Taps t[G];
 #pragma unroll
-        for (int k = 0; k < G; k++) {  // coalesced rows: ref_depth, obj_gray, ref_sigma
+        for (int k = 0; k < G; k++) {  // coalesced rows: ref_depth, obj_gray, 1/depth, weight (index clamped: no branch)
             const int i = base + (g0 + k) * 256;
-            const bool in = i < npix;
-            d[k] = in ? dep[i] : 0.0f;
-            I1[k] = in ? obj[i] : kInvalid;
-            sg[k] = in ? sig[i] : 1.0f;
+            const int ic = i < npix ? i : npix - 1;
+            d[k] = dep[ic];
+            I1[k] = obj[ic];
+            iz[k] = izp[ic];
+            wg[k] = wgp[ic];
         }
 #pragma unroll
         for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
             const int i = base + (g0 + k) * 256;
-            split_index(i < npix ? i : 0, w, a.inv_w, xs[k], ys[k]);
-            gate[k] = (i < npix) && gn_gate(a.prm, xs[k], ys[k], d[k], I1[k]);
+            split_index(i < npix ? i : npix - 1, w, a.inv_w, xs[k], ys[k]);
+            // gn_gate (optimize.cpp:33-48) written with bitwise ops so it stays a predicate, not a branch
+            const int crop_ok = (a.prm.crop == 0) | ((xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100));
+            gate[k] = (i < npix) & (crop_ok != 0) & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
             warp(pose, a.k, (float)xs[k], (float)ys[k], d[k], u[k], v[k]);
-            inter[k] = gate[k] && u[k] >= 1.0f && v[k] >= 1.0f && u[k] < wlim && v[k] < hlim;  // false for NaN
+            inter[k] = gate[k] & (u[k] >= 1.0f) & (v[k] >= 1.0f) & (u[k] < wlim) & (v[k] < hlim);  // false for NaN
             x0[k] = inter[k] ? (int)u[k] : 1;
             y0[k] = inter[k] ? (int)v[k] : 1;
             const float* p = refp + (y0[k] * w + x0[k]);
@@ -260,19 +289,31 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             // predicated accumulation: rejected pixels add exact zeros, so no control flow merges the 29 accumulators
             const bool ok = s > 0;
             float J[6], r, rw;
-            gn_jacobian(a.k, a.prm, xs[k], ys[k], d[k], gx, gy, I1[k], I2, sg[k], J, r, rw);
+            gn_jacobian_pre(a.k, xs[k], ys[k], d[k], iz[k], wg[k], gx, gy, I1[k], I2, J, r, rw);
 #pragma unroll
             for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
             acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
-            if (a.mask && ok) a.mask[img_off + base + (g0 + k) * 256] = 1;
+            if (MASK && ok) a.mask[img_off + base + (g0 + k) * 256] = 1;
         }
     }
     // wave reduction (DPP), then 4 waves through LDS in fixed order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // step-major order: the 29 independent chains interleave, so no DPP read follows its own write (no s_nop)
 #pragma unroll
-    for (int c = 0; c < 29; c++) {
-        const float s = wave_sum_to_lane63(acc.a[c]);
-        if (lane == 63) red[wave][c] = s;
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x111, 0xf>(acc.a[c]);  // row_shr:1
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x112, 0xf>(acc.a[c]);  // row_shr:2
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x114, 0xf>(acc.a[c]);  // row_shr:4
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x118, 0xf>(acc.a[c]);  // row_shr:8
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x142, 0xa>(acc.a[c]);  // row_bcast:15 -> rows 1 and 3
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x143, 0xc>(acc.a[c]);  // row_bcast:31 -> rows 2 and 3
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 29; c++) red[wave][c] = acc.a[c];
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -280,6 +321,131 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
         float s = 0.0f;
         if (c < 29) s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
         a.partials[((size_t)seq * a.nblk + blk) * 32 + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_track_gn_tile: same arithmetic as k_track_gn, different data movement.  A workgroup owns a 64 x (4*PPT)
+// pixel tile; it first issues ALL of its global loads in one burst -- the coalesced rows of its own pixels and
+// the reference-gray patch (tile grown by `margin` pixels plus the 4x4 tap footprint) into LDS -- then, after one
+// barrier, every warped sample is a short-latency LDS read instead of an L1/L2 gather.  Pixels whose footprint
+// leaves the staged patch (large motion) gather from global memory; borders / INVALID taps take the generic
+// sampler.  All three sources hold the same floats, so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int PPT, bool MASK>
+__global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [0,128): reduction scratch, then the patch
+    float* red = smem;
+    float* patch = smem + 128;
+    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+    const int seq = id / a.nblk, tile = id - seq * a.nblk;
+    const SeqState& st = a.state[seq];
+    if (!a.ignore_active && st.active == 0) return;  // converged sequences cost nothing
+    const Pose pose = st.pose;
+    const int w = a.w, h = a.h;
+    constexpr int TH = 4 * PPT;
+    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+    const int tx0 = txi * 64, ty0 = tyi * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t img_off = (size_t)seq * w * h;
+    const float* __restrict__ obj = a.obj_gray + img_off;
+    const float* __restrict__ dep = a.ref_depth + img_off;
+    const float* __restrict__ izp = a.ref_iz + img_off;
+    const float* __restrict__ wgp = a.ref_wgt + img_off;
+    const float* __restrict__ refp = a.ref_gray + img_off;
+
+    // ---- one burst of global loads: own pixels (registers) + reference patch (LDS) ----
+    const int x = tx0 + lane;
+    float d[PPT], I1[PPT], iz[PPT], wg[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int y = ty0 + wave + 4 * k;
+        const int xc = x < w ? x : w - 1, yc = y < h ? y : h - 1;  // clamped: no branch, gated out below
+        const int i = yc * w + xc;
+        d[k] = dep[i];
+        I1[k] = obj[i];
+        iz[k] = izp[i];
+        wg[k] = wgp[i];
+    }
+    const int M = a.margin, PW = 64 + 2 * M + 3;
+    const int px0 = max(tx0 - M - 1, 0), px1 = min(tx0 + 64 + M + 2, w);  // staged columns [px0, px1)
+    const int py0 = max(ty0 - M - 1, 0), py1 = min(ty0 + TH + M + 2, h);  // staged rows    [py0, py1)
+    for (int r = py0 + wave; r < py1; r += 4) {
+        const float* src = refp + r * w;
+        float* dst = patch + (r - py0) * PW;
+        for (int c = px0 + lane; c < px1; c += 64) dst[c - px0] = src[c];
+    }
+    __syncthreads();
+
+    const float wlim = (float)(w - 2), hlim = (float)(h - 2);
+    Acc29 acc;
+    acc.zero();
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int y = ty0 + wave + 4 * k;
+        const int crop_ok = (a.prm.crop == 0) | ((x >= 20) & (x <= 140) & (y >= 20) & (y <= 100));
+        const bool gate = (x < w) & (y < h) & (crop_ok != 0) & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
+        float u, v;
+        warp(pose, a.k, (float)x, (float)y, d[k], u, v);
+        const bool inter = gate & (u >= 1.0f) & (v >= 1.0f) & (u < wlim) & (v < hlim);  // false for NaN
+        const int x0 = inter ? (int)u : 1, y0 = inter ? (int)v : 1;
+        const bool inpatch = inter & (x0 - 1 >= px0) & (x0 + 2 < px1) & (y0 - 1 >= py0) & (y0 + 2 < py1);
+        Taps t;
+        {  // LDS taps (address forced inside the patch for lanes that will not use them)
+            const int lx = inpatch ? x0 - px0 : 1, ly = inpatch ? y0 - py0 : 1;
+            const float* q = patch + ly * PW + lx;
+            t.ra.x = q[-PW]; t.ra.y = q[-PW + 1];
+            t.rb.x = q[-1]; t.rb.y = q[0]; t.rb.z = q[1]; t.rb.w = q[2];
+            t.rc.x = q[PW - 1]; t.rc.y = q[PW]; t.rc.z = q[PW + 1]; t.rc.w = q[PW + 2];
+            t.rd.x = q[2 * PW]; t.rd.y = q[2 * PW + 1];
+        }
+        if (inter & !inpatch) {  // footprint left the staged patch (large motion): gather from global memory
+            const float* p = refp + (y0 * w + x0);
+            t.ra = *reinterpret_cast<const f2u*>(p - w);
+            t.rb = *reinterpret_cast<const f4u*>(p - 1);
+            t.rc = *reinterpret_cast<const f4u*>(p + w - 1);
+            t.rd = *reinterpret_cast<const f2u*>(p + 2 * w);
+        }
+        float I2 = 0.0f, gx = 0.0f, gy = 0.0f;
+        int s = gn_sample_fast(t, u, v, x0, y0, I2, gx, gy);
+        s = gate ? (inter ? s : -1) : 0;
+        if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
+            float o3[3];
+            s = gn_sample_slow(refp, w, h, d[k], u, v, o3) ? 1 : 0;
+            I2 = o3[0]; gx = o3[1]; gy = o3[2];
+        }
+        const bool ok = s > 0;
+        float J[6], r, rw;
+        gn_jacobian_pre(a.k, x, y, d[k], iz[k], wg[k], gx, gy, I1[k], I2, J, r, rw);
+#pragma unroll
+        for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
+        acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
+        if (MASK && ok) a.mask[img_off + y * w + x] = 1;
+    }
+    // wave reduction (DPP, step-major), then the 4 waves through LDS in fixed order
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x111, 0xf>(acc.a[c]);
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x112, 0xf>(acc.a[c]);
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x114, 0xf>(acc.a[c]);
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x118, 0xf>(acc.a[c]);
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x142, 0xa>(acc.a[c]);
+#pragma unroll
+    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x143, 0xc>(acc.a[c]);
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 29; c++) red[wave * 32 + c] = acc.a[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        float s = 0.0f;
+        if (c < 29) s = ((red[c] + red[32 + c]) + red[64 + c]) + red[96 + c];
+        a.partials[((size_t)seq * a.nblk + tile) * 32 + c] = s;
     }
 }
 
@@ -627,15 +793,53 @@ void launch_warp_image(const float* gray, const float* depth, int w, int h, cons
 
 int gn_blocks_per_seq(int w, int h, int ppt) { return (int)cdiv((unsigned)(w * h), 256u * (unsigned)ppt); }
 
-void launch_track_gn(const GnArgs& a, int n_seq, int ppt, hipStream_t s)
+template <int PPT, int G>
+static void launch_track_gn_t(const GnArgs& a, const dim3& grid, hipStream_t s)
 {
-    const dim3 grid((unsigned)a.nblk * (unsigned)n_seq), block(256);
-    switch (ppt) {
-        case 1: hipLaunchKernelGGL(k_track_gn<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_track_gn<2>, grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(k_track_gn<4>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(k_track_gn<8>, grid, block, 0, s, a); break;
+    if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_track_gn<PPT, G, false>), grid, dim3(256), 0, s, a);
+}
+
+void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s)
+{
+    const dim3 grid((unsigned)a.nblk * (unsigned)n_seq);
+    switch (ppt * 10 + group) {
+        case 11: launch_track_gn_t<1, 1>(a, grid, s); break;
+        case 21: launch_track_gn_t<2, 1>(a, grid, s); break;
+        case 22: launch_track_gn_t<2, 2>(a, grid, s); break;
+        case 41: launch_track_gn_t<4, 1>(a, grid, s); break;
+        case 42: launch_track_gn_t<4, 2>(a, grid, s); break;
+        case 44: launch_track_gn_t<4, 4>(a, grid, s); break;
+        case 81: launch_track_gn_t<8, 1>(a, grid, s); break;
+        case 82: launch_track_gn_t<8, 2>(a, grid, s); break;
+        default: launch_track_gn_t<8, 4>(a, grid, s); break;
     }
+}
+
+template <int PPT>
+static void launch_track_gn_tile_t(const GnArgs& a, const dim3& grid, hipStream_t s)
+{
+    const size_t lds = (128 + (size_t)(4 * PPT + 2 * a.margin + 3) * (64 + 2 * a.margin + 3)) * sizeof(float);
+    if (a.mask) hipLaunchKernelGGL((k_track_gn_tile<PPT, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_track_gn_tile<PPT, false>), grid, dim3(256), lds, s, a);
+}
+
+void launch_track_gn_tile(const GnArgs& a, int n_seq, int ppt, hipStream_t s)
+{
+    const dim3 grid((unsigned)a.nblk * (unsigned)n_seq);
+    switch (ppt) {
+        case 1: launch_track_gn_tile_t<1>(a, grid, s); break;
+        case 2: launch_track_gn_tile_t<2>(a, grid, s); break;
+        case 4: launch_track_gn_tile_t<4>(a, grid, s); break;
+        default: launch_track_gn_tile_t<8>(a, grid, s); break;
+    }
+}
+
+void launch_prep_ref(const PrepArgs& a, hipStream_t s)
+{
+    const size_t n = a.level_end[a.levels - 1];
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_prep_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s)

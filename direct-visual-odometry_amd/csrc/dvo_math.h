@@ -190,14 +190,22 @@ struct GnParams {
     int   crop;        // 1 when this level is cropped (optimize.cpp:33-36)
 };
 
-// Jacobian row, residual and weighted residual of one contributing pixel (optimize.cpp:67-89).
-DVO_HD void gn_jacobian(const Intr& k, const GnParams& prm, int x, int y, float d, float gx, float gy, float I1, float I2,
-                        float sigma, float J[6], float& r, float& rw)
+// weight of reliability, optimize.cpp:83-84: step / clamp(sigma, 0.01, 0.5)
+DVO_HD float gn_weight(float step, float sigma_min, float sigma_max, float sigma)
+{
+    const float sc = sigma < sigma_min ? sigma_min : (sigma_max < sigma ? sigma_max : sigma);
+    return step / sc;
+}
+
+// Jacobian row, residual and weighted residual of one contributing pixel (optimize.cpp:67-89), given the
+// per-pixel constants iz = 1.0f / depth (the six divisions by z of optimize.cpp:70-74 share this reciprocal, D8)
+// and wgt = gn_weight(...).
+DVO_HD void gn_jacobian_pre(const Intr& k, int x, int y, float d, float iz, float wgt, float gx, float gy, float I1,
+                            float I2, float J[6], float& r, float& rw)
 {
     float X, Y, Z;
     back_project(k, (float)x, (float)y, d, X, Y, Z);
     const float fgx = k.fx * gx, fgy = k.fy * gy;
-    const float iz = 1.0f / Z;  // the six divisions by z of optimize.cpp:70-74 share one reciprocal (D8)
     const float xz = X * iz, yz = Y * iz;
     J[0] = fgx * iz;
     J[1] = fgy * iz;
@@ -206,8 +214,13 @@ DVO_HD void gn_jacobian(const Intr& k, const GnParams& prm, int x, int y, float 
     J[4] = (fgx * fmaf(xz, xz, 1.0f)) + ((fgy * xz) * yz);
     J[5] = fmaf(fgy, xz, -(fgx * yz));
     r = I2 - I1;
-    const float sc = sigma < prm.sigma_min ? prm.sigma_min : (prm.sigma_max < sigma ? prm.sigma_max : sigma);
-    rw = r * (prm.step / sc);
+    rw = r * wgt;
+}
+
+DVO_HD void gn_jacobian(const Intr& k, const GnParams& prm, int x, int y, float d, float gx, float gy, float I1, float I2,
+                        float sigma, float J[6], float& r, float& rw)
+{
+    gn_jacobian_pre(k, x, y, d, 1.0f / d, gn_weight(prm.step, prm.sigma_min, prm.sigma_max, sigma), gx, gy, I1, I2, J, r, rw);
 }
 
 // The gates of optimize.cpp:33-48 that do not need the warp.  (double)d < 0.20  <=>  d < 0.2f for float d.

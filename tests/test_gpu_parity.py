@@ -337,3 +337,18 @@ def test_bad_arguments_return_status_not_abort():
     with pytest.raises(dvo.DvoError):
         vo.keyframeInfo(0)      # FrameHistory::operator[] .at() throws in the reference (frame.hpp:176)
     vo.close()
+
+
+# ---------------------------------------------------------------- kernel variants (tiling / LDS patch) agree
+@pytest.mark.parametrize("lds,ppt,group", [(0, 1, 1), (0, 2, 2), (0, 4, 1), (0, 4, 4), (0, 8, 4), (8, 1, 0), (8, 4, 0), (2, 2, 0), (16, 8, 0)])
+def test_gn_kernel_variants_match_oracle(lds, ppt, group):
+    g, d, s, _ = frames()
+    ref = orc.OFrame(g[0], d[0], s[0], K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], s[1], K640, 4, 1)
+    rg = ref.gray(3); rg[100:104, 150:160] = INV           # force the generic sampler inside the image too
+    # large motion: many footprints leave a margin-2 patch and some leave the image
+    xi = np.array([0.02, -0.015, 0.01, 0.01, 0.012, -0.02], np.float32)
+    cfg = dvo.default_config(gn_use_lds_patch=lds, gn_pixels_per_thread=ppt, gn_gather_group=group)
+    for level in (1, 3):
+        rgl = rg if level == 3 else ref.gray(level)
+        _gn_compare(obj.gray(level), rgl, ref.depth(level), ref.sigma(level), ref.K(level), xi, level, cfg=cfg)

@@ -20,6 +20,8 @@ ap.add_argument("--level", type=int, default=3)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--ppt", type=int, default=0)
 ap.add_argument("--sigma", type=float, default=0.1)
+ap.add_argument("--group", type=int, default=0)
+ap.add_argument("--lds", type=int, default=-1, help="-1 auto, 0 global gathers, N>0 LDS patch margin")
 ap.add_argument("--distinct", type=int, default=4, help="distinct rendered sequences (tiled to --batch)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -35,7 +37,7 @@ gray = torch.stack(gs, 1).repeat(1, rep, 1, 1)[:, :a.batch].contiguous()   # [2]
 depth = torch.stack(ds, 1).repeat(1, rep, 1, 1)[:, :a.batch].contiguous()
 sigma = torch.full_like(gray, a.sigma)
 torch.cuda.synchronize()
-cfg = dvo.default_config(stream=torch.cuda.current_stream().cuda_stream, gn_pixels_per_thread=a.ppt)
+cfg = dvo.default_config(stream=torch.cuda.current_stream().cuda_stream, gn_pixels_per_thread=a.ppt, gn_gather_group=a.group, gn_use_lds_patch=a.lds)
 bt = dvo.Batch(a.batch, K, W, H, 4, 1, cfg=cfg)
 for f in range(2):
     bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
