@@ -276,20 +276,33 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             t[k].rc = *reinterpret_cast<const f4u*>(p + w - 1);
             t[k].rd = *reinterpret_cast<const f2u*>(p + 2 * w);
         }
+        // The G pixels are sampled in ONE straight-line block (independent chains interleave: ILP), the rare generic
+        // sampler runs in a single separate region, then Jacobians and sums again in one straight-line block.
+        float I2[G], gx[G], gy[G];
+        int st[G];
+        bool any_slow = false;
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            float I2 = 0.0f, gx = 0.0f, gy = 0.0f;
-            int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2, gx, gy);
-            s = gate[k] ? (inter[k] ? s : -1) : 0;
-            if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
-                float o3[3];
-                s = gn_sample_slow(refp, w, h, d[k], u[k], v[k], o3) ? 1 : 0;
-                I2 = o3[0]; gx = o3[1]; gy = o3[2];
+            const int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2[k], gx[k], gy[k]);
+            st[k] = gate[k] ? (inter[k] ? s : -1) : 0;
+            any_slow |= st[k] < 0;
+        }
+        if (any_slow) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                if (st[k] < 0) {
+                    float o3[3];
+                    st[k] = gn_sample_slow(refp, w, h, d[k], u[k], v[k], o3) ? 1 : 0;
+                    I2[k] = o3[0]; gx[k] = o3[1]; gy[k] = o3[2];
+                }
             }
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {
             // predicated accumulation: rejected pixels add exact zeros, so no control flow merges the 29 accumulators
-            const bool ok = s > 0;
+            const bool ok = st[k] > 0;
             float J[6], r, rw;
-            gn_jacobian_pre(a.k, xs[k], ys[k], d[k], iz[k], wg[k], gx, gy, I1[k], I2, J, r, rw);
+            gn_jacobian_pre(a.k, xs[k], ys[k], d[k], iz[k], wg[k], gx[k], gy[k], I1[k], I2[k], J, r, rw);
 #pragma unroll
             for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
             acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);

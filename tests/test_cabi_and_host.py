@@ -1,0 +1,89 @@
+"""CPU tests of the drop-in boundary: libdvo.so loads, exports every symbol include/dvo.h declares, and FAILS
+LOUDLY (no CPU fallback) when asked to compute without a GPU.  No compute call succeeds here by design."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dvo_amd as dvo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "dvo.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvo_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = dvo.lib()
+    names = _header_functions()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(dvo.EXPORTS) == names          # the Python binding list and the header agree
+
+
+def test_config_defaults_are_the_reference_literals():
+    c = dvo.default_config()
+    assert c.max_iterations == 15 and abs(c.min_update - 5e-4) < 1e-9 and abs(c.min_residual - 5e-3) < 1e-9  # tracker.cpp:16-19
+    assert (c.step_default, c.step_level1, c.step_level2) == (2.0, 1.5, 1.0)                                # optimize.cpp:22-26
+    assert abs(c.sigma_min - 0.01) < 1e-9 and c.sigma_max == 0.5 and abs(c.min_depth - 0.2) < 1e-7          # optimize.cpp:39,83
+    assert abs(c.keyframe_min_translation - 0.02) < 1e-9 and c.keyframe_max_frames == 6                     # mapper.cpp:12-13
+    assert c.crop_enable == 1 and c.fixed_iterations == 0
+    assert C.sizeof(dvo.Config) == 96 or C.sizeof(dvo.Config) % 8 == 0
+
+
+def test_status_strings():
+    L = dvo.lib()
+    assert L.dvo_status_string(0) == b"ok"
+    assert b"no CPU fallback" in L.dvo_status_string(3)
+    assert b"gfx950" in L.dvo_version()
+
+
+@pytest.mark.skipif(dvo.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    K = np.array([525, 0, 319.5, 0, 525, 239.5, 0, 0, 1], np.float32)
+    with pytest.raises(dvo.DvoError, match="no HIP device|no CPU fallback"):
+        dvo.VisualOdometry(K, 640, 480)
+    with pytest.raises(dvo.DvoError):
+        dvo.Batch(4, K, 640, 480)
+    img = np.zeros((8, 8), np.float32)
+    with pytest.raises(dvo.DvoError):
+        dvo.Convert.cullImage(img, 1)
+    with pytest.raises(dvo.DvoError):
+        dvo.se3.exp(np.zeros(6, np.float32))
+
+
+def test_bad_arguments_are_status_codes():
+    L = dvo.lib()
+    assert L.dvo_vo_create(None, 640, 480, None, None) == 1          # DVO_ERR_BAD_ARGUMENT, never abort()
+    assert L.dvo_op_cull_image(0, None, 4, 4, 1, None) == 1
+    assert L.dvo_batch_destroy(None) == 0 and L.dvo_vo_destroy(None) == 0
+    assert L.dvo_vo_keyframe_count(None) == 0
+
+
+def test_product_never_references_the_oracle():
+    # the product path must not link, load or call anything under oracle/
+    pkg = os.path.join(ROOT, "direct-visual-odometry_amd")
+    for sub, exts in (("csrc", (".h", ".hip", ".cpp")), ("dvo_amd", (".py",))):
+        for fn in os.listdir(os.path.join(pkg, sub)):
+            if fn.endswith(exts):
+                txt = open(os.path.join(pkg, sub, fn)).read()
+                assert "liboracle" not in txt and "dvo_oracle" not in txt and "import orc" not in txt, fn
+    out = os.popen("ldd %s" % dvo.LIB_PATH).read()
+    assert "oracle" not in out
+
+
+def test_cpp_facade_header_compiles():
+    # include/dvo.hpp (System::VisualOdometry facade) must be valid C++17 against include/dvo.h
+    import subprocess, tempfile
+    src = '#include "dvo.hpp"\nint main(){ dvo::Mat3 K{}; (void)K; auto c = dvo::default_config(); return c.max_iterations == 15 ? 0 : 1; }\n'
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
+        f.write(src)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 0, r.stderr
