@@ -468,21 +468,27 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
 //   partial sums -> double, fixed order;  xi_update = H^+ g (LDL^T / eigen pseudo-inverse, double);
 //   xi <- log(exp(xi) exp(xi_update)) unless NaN (testXi);  pose <- exp(-xi);  stop tests.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gn_solve(SolveArgs a)
+__global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
 {
+    __shared__ double part[8][32];
     __shared__ double tot[32];
     const int seq = blockIdx.x;
     SeqState& st = a.state[seq];
     if (!a.ignore_active && st.active == 0) return;
-    const int c = threadIdx.x;
-    if (c < 32) {
+    // second reduction stage: 8 groups of 32 lanes stride over the workgroup partials (many loads in flight instead
+    // of one dependent chain), then the 8 group sums are added in a fixed order -> still bit-reproducible
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    {
         double s = 0.0;
         if (c < 29) {
             const float* p = a.partials + (size_t)seq * a.nblk * 32 + c;
-            for (int b = 0; b < a.nblk; b++) s += (double)p[(size_t)b * 32];
+            for (int b = grp; b < a.nblk; b += 8) s += (double)p[(size_t)b * 32];
         }
-        tot[c] = s;
+        part[grp][c] = s;
     }
+    __syncthreads();
+    if (threadIdx.x < 32)
+        tot[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
     __syncthreads();
     if (threadIdx.x != 0) return;
 
@@ -857,7 +863,7 @@ void launch_prep_ref(const PrepArgs& a, hipStream_t s)
 
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(256), 0, s, a);
 }
 
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s)
