@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     return ap.parse_args()
 
 
@@ -122,12 +123,14 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # config 5: gather every rank's poses over RCCL/xGMI (tens of KB: latency bound)
-        allp = torch.empty((world,) + tuple(poses_out.shape), dtype=torch.float32, device=dev)
+        from dvo_amd import shard
+        local = poses_out.permute(1, 0, 2).contiguous()  # [sequence][frame][6]
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        dist.all_gather_into_tensor(allp, poses_out)
+        allp, lens = shard.gather_poses(local)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        assert allp.shape[0] == B * world and int(lens.min().item()) == a.steps
     dt = float(tmax.item())
     fps = B * a.steps * world / dt
     log0 = batch.last_track_log(0)
@@ -145,6 +148,22 @@ def main():
                    "fixed_iterations": a.fixed_iters, "iterations_per_level_seq0": log0["n_iter"],
                    "poses_finite": finite, "gather_ms": gather_ms, "datagen_s": round(t_gen, 2)},
     }
+
+    # ---- PCIe-inclusive rate (reported in config, never `value`): the same steps fed from pinned HOST buffers ----
+    if a.pcie_steps > 0:
+        hb = dvo.Batch(B, K, W, H, levels, culls, cfg=cfg)
+        host = [(gray[f].cpu().pin_memory(), depth[f].cpu().pin_memory(), sigma[f].cpu().pin_memory()) for f in range(min(F, 3))]
+        def hpush(k):
+            g_, d_, s_ = host[ring_index(k, len(host))]
+            hb.push_host(g_.numpy(), d_.numpy(), s_.numpy())
+        hpush(0); hpush(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.pcie_steps):
+            hpush(2 + k)
+        hb.synchronize()
+        out["config"]["pcie_inclusive_fps"] = B * a.pcie_steps / (time.perf_counter() - t1)
+        hb.close()
 
     # ---- roofline of the dominant kernel (k_track_gn): HIP events around every launch of an identical pass ----
     if not a.no_roofline:

@@ -30,9 +30,13 @@
  *  D6 initial mono depth (cv::randn, frame.hpp:17-21) is an explicit input.
  *  D7 forEach bodies are executed sequentially in raster order (the reference
  *     races on shared state, optimize.cpp:8,64,80; implement.cpp:250-252).
- *  D8 multi-term float sums are evaluated as explicit fmaf chains (the
- *     reference is built -Ofast -march=native, i.e. contracted anyway); the
- *     order is fixed in DESIGN.md §3 so CPU and GPU agree bit for bit per pixel.
+ *  D8 multi-term float sums are evaluated as explicit fmaf chains, and divisions
+ *     that share a divisor as one correctly rounded reciprocal times the
+ *     numerators (1/fx, 1/fy, 1/Z' in project, 1/z in optimize.cpp:70-74): the
+ *     reference is built -Ofast -march=native, i.e. -ffp-contract=fast and
+ *     -freciprocal-math.  The order is fixed in DESIGN.md §3 so CPU and GPU
+ *     agree bit for bit per pixel.
+ *  D10 depthEstimate (implement.cpp:49-71) is evaluated in double from float inputs.
  *  D9 VisualOdometry(gray,depth,sigma,K) builds its keyframe as Frame(...,4,1)
  *     (system.hpp:30) while odometrize() builds Frame(...,3,2) (system.hpp:47), so
  *     the reference throws at m_scenes.at(3) on the first tracked frame; here that
