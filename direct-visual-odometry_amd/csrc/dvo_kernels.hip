@@ -244,6 +244,18 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     acc.zero();
     // G pixels per thread have their gathers in flight together (memory-level parallelism hides the L2/HBM latency)
     static_assert(PPT % G == 0, "PPT must be a multiple of G");
+    // every coalesced row load of this thread's PPT pixels is issued up front (independent of the pose): one exposed
+    // memory round trip per wave instead of one per group
+    float dA[PPT], I1A[PPT], izA[PPT], wgA[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, 1/depth, weight (index clamped: no branch)
+        const int i = base + k * 256;
+        const int ic = i < npix ? i : npix - 1;
+        dA[k] = dep[ic];
+        I1A[k] = obj[ic];
+        izA[k] = izp[ic];
+        wgA[k] = wgp[ic];
+    }
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
         float d[G], I1[G], iz[G], wg[G], u[G], v[G];
@@ -251,13 +263,8 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
         bool gate[G], inter[G];
         Taps t[G];
 #pragma unroll
-        for (int k = 0; k < G; k++) {  // coalesced rows: ref_depth, obj_gray, 1/depth, weight (index clamped: no branch)
-            const int i = base + (g0 + k) * 256;
-            const int ic = i < npix ? i : npix - 1;
-            d[k] = dep[ic];
-            I1[k] = obj[ic];
-            iz[k] = izp[ic];
-            wg[k] = wgp[ic];
+        for (int k = 0; k < G; k++) {
+            d[k] = dA[g0 + k]; I1[k] = I1A[g0 + k]; iz[k] = izA[g0 + k]; wg[k] = wgA[g0 + k];
         }
 #pragma unroll
         for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
