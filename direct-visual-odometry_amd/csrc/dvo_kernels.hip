@@ -43,6 +43,83 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed wave64 reduction of 29 per-lane accumulators (fixed order, deterministic).
+// A plain butterfly spends 6 DPP adds per value (174 VALU per wave) although half of the lanes carry useful data
+// after every step.  Here every step also PACKS two registers into one, so the work halves each time (68 VALU):
+//   32-lane step: v_permlane32_swap (gfx950) of a register pair + 1 add  -> low half = sum of A, high half = sum of B
+//   16-lane step: v_permlane16_swap of a pair + 1 add                    -> one value per 16-lane row
+//    8-lane step: row_shl:8 / row_shr:8 DPP adds of a pair + bank-masked merge -> one value per 8 lanes
+//    4-lane step: row_shl:4 / row_shr:4, same                            -> one value per quad (2 registers left)
+//    quad steps : quad_perm adds                                         -> every lane of a quad holds its value's total
+// Lane L of output register q then holds value  16 q + {0,8,4,12}[(L>>2)&3] + {0,2,1,3}[L>>4].
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lanes selected by BANK_MASK (4-lane banks inside each 16-lane row) take `hi`, the others keep `lo`
+template <int BANK_MASK>
+__device__ __forceinline__ float bank_merge(float lo, float hi)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0xE4 /*quad_perm identity*/, 0xf, BANK_MASK, false));
+}
+
+__device__ __forceinline__ int packed_slot_index(int lane, int q)
+{
+    const int quad = (lane >> 2) & 3, row = lane >> 4;
+    const int qm = (quad == 0) ? 0 : (quad == 1) ? 8 : (quad == 2) ? 4 : 12;
+    const int rm = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;
+    return 16 * q + qm + rm;
+}
+
+// v[0..28] in, out0/out1 as described above
+__device__ __forceinline__ void wave_reduce29_packed(const float* v, float& out0, float& out1)
+{
+    float A[15];
+#pragma unroll
+    for (int j = 0; j < 14; j++) A[j] = swap32_add(v[2 * j], v[2 * j + 1]);
+    A[14] = swap32_add(v[28], 0.0f);
+    float B[8];
+#pragma unroll
+    for (int m = 0; m < 7; m++) B[m] = swap16_add(A[2 * m], A[2 * m + 1]);
+    B[7] = swap16_add(A[14], 0.0f);
+    float Cc[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const float lo = B[2 * n] + dpp_mov<0x108>(B[2 * n]);          // row_shl:8 -> lanes 0-7 of each row
+        const float hi = B[2 * n + 1] + dpp_mov<0x118>(B[2 * n + 1]);  // row_shr:8 -> lanes 8-15
+        Cc[n] = bank_merge<0xC>(lo, hi);
+    }
+    float D[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const float lo = Cc[2 * q] + dpp_mov<0x104>(Cc[2 * q]);          // row_shl:4 -> lanes 0-3, 8-11
+        const float hi = Cc[2 * q + 1] + dpp_mov<0x114>(Cc[2 * q + 1]);  // row_shr:4 -> lanes 4-7, 12-15
+        D[q] = bank_merge<0xA>(lo, hi);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        D[q] = D[q] + dpp_mov<0xB1>(D[q]);  // quad_perm [1,0,3,2]
+        D[q] = D[q] + dpp_mov<0x4E>(D[q]);  // quad_perm [2,3,0,1]
+    }
+    out0 = D[0];
+    out1 = D[1];
+}
+
 __device__ __forceinline__ void split_index(int i, int w, float inv_w, int& x, int& y)
 {  // i < 2^24: y = i / w without an integer divide; the +-1 fix-up is branch free
     y = (int)((float)i * inv_w);
@@ -250,11 +327,11 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
 #pragma unroll
     for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, 1/depth, weight (index clamped: no branch)
         const int i = base + k * 256;
-        const int ic = i < npix ? i : npix - 1;
-        dA[k] = dep[ic];
-        I1A[k] = obj[ic];
-        izA[k] = izp[ic];
-        wgA[k] = wgp[ic];
+        const unsigned ic = (unsigned)(i < npix ? i : npix - 1) * 4u;  // byte offset: SGPR base + 32-bit VGPR offset
+        dA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dep) + ic);
+        I1A[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(obj) + ic);
+        izA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(izp) + ic);
+        wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);
     }
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
@@ -277,11 +354,13 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             inter[k] = gate[k] & (u[k] >= 1.0f) & (v[k] >= 1.0f) & (u[k] < wlim) & (v[k] < hlim);  // false for NaN
             x0[k] = inter[k] ? (int)u[k] : 1;
             y0[k] = inter[k] ? (int)v[k] : 1;
-            const float* p = refp + (y0[k] * w + x0[k]);
-            t[k].ra = *reinterpret_cast<const f2u*>(p - w);
-            t[k].rb = *reinterpret_cast<const f4u*>(p - 1);
-            t[k].rc = *reinterpret_cast<const f4u*>(p + w - 1);
-            t[k].rd = *reinterpret_cast<const f2u*>(p + 2 * w);
+            // unsigned 32-bit element offsets from the wave-uniform base: SGPR-base + VGPR-offset addressing, no 64-bit VALU math
+            const unsigned c = (unsigned)(y0[k] * w + x0[k]) * 4u, uw = (unsigned)w * 4u;  // BYTE offsets (< 2^26)
+            const char* rb8 = reinterpret_cast<const char*>(refp);
+            t[k].ra = *reinterpret_cast<const f2u*>(rb8 + (c - uw));
+            t[k].rb = *reinterpret_cast<const f4u*>(rb8 + (c - 4u));
+            t[k].rc = *reinterpret_cast<const f4u*>(rb8 + (c + uw - 4u));
+            t[k].rd = *reinterpret_cast<const f2u*>(rb8 + (c + 2u * uw));
         }
         // The G pixels are sampled in ONE straight-line block (independent chains interleave: ILP), the rare generic
         // sampler runs in a single separate region, then Jacobians and sums again in one straight-line block.
@@ -318,22 +397,13 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     }
     // wave reduction (DPP), then 4 waves through LDS in fixed order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // step-major order: the 29 independent chains interleave, so no DPP read follows its own write (no s_nop)
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x111, 0xf>(acc.a[c]);  // row_shr:1
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x112, 0xf>(acc.a[c]);  // row_shr:2
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x114, 0xf>(acc.a[c]);  // row_shr:4
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x118, 0xf>(acc.a[c]);  // row_shr:8
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x142, 0xa>(acc.a[c]);  // row_bcast:15 -> rows 1 and 3
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x143, 0xc>(acc.a[c]);  // row_bcast:31 -> rows 2 and 3
-    if (lane == 63) {
-#pragma unroll
-        for (int c = 0; c < 29; c++) red[wave][c] = acc.a[c];
+    {
+        float o0, o1;
+        wave_reduce29_packed(acc.a, o0, o1);
+        if ((lane & 3) == 0) {  // one lane per quad publishes its value (slots 29..31 are zero padding)
+            red[wave][packed_slot_index(lane, 0)] = o0;
+            red[wave][packed_slot_index(lane, 1)] = o1;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -444,21 +514,13 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         if (MASK && ok) a.mask[img_off + y * w + x] = 1;
     }
     // wave reduction (DPP, step-major), then the 4 waves through LDS in fixed order
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x111, 0xf>(acc.a[c]);
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x112, 0xf>(acc.a[c]);
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x114, 0xf>(acc.a[c]);
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x118, 0xf>(acc.a[c]);
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x142, 0xa>(acc.a[c]);
-#pragma unroll
-    for (int c = 0; c < 29; c++) acc.a[c] = dpp_step<0x143, 0xc>(acc.a[c]);
-    if (lane == 63) {
-#pragma unroll
-        for (int c = 0; c < 29; c++) red[wave * 32 + c] = acc.a[c];
+    {
+        float o0, o1;
+        wave_reduce29_packed(acc.a, o0, o1);
+        if ((lane & 3) == 0) {
+            red[wave * 32 + packed_slot_index(lane, 0)] = o0;
+            red[wave * 32 + packed_slot_index(lane, 1)] = o1;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
