@@ -14,6 +14,7 @@ struct SeqState {
     Pose  pose;    // exp(-xi) rounded to float: what every warp of the level uses
     int   active;  // 0 once the level's stop test fired (tracker.cpp:68-73)
     int   iter;    // iterations done on the current level
+    double Tc[12]; // exp(+xi) in double (R row major, then t): carried so each iteration evaluates 2 exps instead of 4
 };
 
 struct PyramidArgs {

@@ -543,7 +543,15 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
     __shared__ double tot[32];
     const int seq = blockIdx.x;
     SeqState& st = a.state[seq];
-    if (!a.ignore_active && st.active == 0) return;
+    // Everything this kernel needs from memory is requested up front (a fresh kernel starts with cold caches: each
+    // dependent round trip costs ~2 us): the state of the sequence and the partial rows.  The active test comes after.
+    const int was_active = st.active, it_prev = st.iter;
+    float xi[6];
+    double Tc[12];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Tc[i] = st.Tc[i];
     // second reduction stage: 8 groups of 32 lanes stride over the workgroup partials (many loads in flight instead
     // of one dependent chain), then the 8 group sums are added in a fixed order -> still bit-reproducible
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -551,7 +559,17 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         double s = 0.0;
         if (c < 29) {
             const float* p = a.partials + (size_t)seq * a.nblk * 32 + c;
-            for (int b = grp; b < a.nblk; b += 8) s += (double)p[(size_t)b * 32];
+            // 8 loads are issued before the first add: one memory round trip per 64 workgroup rows instead of one per row
+            for (int b0 = grp; b0 < a.nblk; b0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int b = b0 + 8 * j;
+                    v[j] = p[(size_t)(b < a.nblk ? b : b0) * 32];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) s += (b0 + 8 * j < a.nblk) ? (double)v[j] : 0.0;
+            }
         }
         part[grp][c] = s;
     }
@@ -560,6 +578,7 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         tot[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
     __syncthreads();
     if (threadIdx.x != 0) return;
+    if (!a.ignore_active && was_active == 0) return;  // converged sequence: nothing to do
 
     const int n_valid = (int)tot[28];
     const double sum_r2 = tot[27];
@@ -569,24 +588,21 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         solve6(tot, tot + 21, upd);
         residual = (float)sum_r2 / (float)n_valid;  // optimize.cpp:98
     }
-    float xi[6], nxt[6];
+    Pose np;
+    // xi <- log(exp(xi) exp(upd)) unless NaN (tracker.cpp:46-51); pose <- exp(-xi) for Stuff::update (optimize.hpp:26-30)
+    if (se3_update_pose(Tc, upd, xi, np)) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
-    se3_concatenate_f(xi, upd, nxt);  // tracker.cpp:46
-    bool ok = true;
+        for (int i = 0; i < 6; i++) st.xi[i] = xi[i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) ok = ok && !(nxt[i] != nxt[i]);  // testXi, util.hpp:34-44
-    if (ok) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { xi[i] = nxt[i]; st.xi[i] = nxt[i]; }
-        pose_from_xi(xi, -1.0f, st.pose);  // Stuff::update -> warp with -xi (optimize.hpp:26-30)
+        for (int i = 0; i < 12; i++) st.Tc[i] = Tc[i];
+        st.pose = np;
     }
     double nrm = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) nrm += (double)upd[i] * (double)upd[i];
     nrm = sqrt(nrm);
 
-    const int it = a.ignore_active ? 0 : st.iter;
+    const int it = a.ignore_active ? 0 : it_prev;
     if (a.log && it < DVO_MAX_ITERATIONS) {
         dvo_track_log& lg = a.log[seq];
         lg.n_iter[a.level] = it + 1;
@@ -627,6 +643,7 @@ __global__ void __launch_bounds__(256) k_track_begin(SeqState* state, dvo_track_
     for (int i = 0; i < 6; i++) st.xi[i] = 0.0f;
     for (int i = 0; i < 9; i++) st.pose.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
     for (int i = 0; i < 3; i++) st.pose.t[i] = 0.0f;
+    for (int i = 0; i < 12; i++) st.Tc[i] = (i < 9 && i % 4 == 0) ? 1.0 : 0.0;
     st.active = 1;
     st.iter = 0;
     if (log) {
@@ -641,8 +658,12 @@ __global__ void k_set_pose(SeqState* state, const float* xi, int n_seq)
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seq) return;
     float x[6];
-    for (int i = 0; i < 6; i++) { x[i] = xi[s * 6 + i]; state[s].xi[i] = x[i]; }
+    double xd[6], R[9], t[3];
+    for (int i = 0; i < 6; i++) { x[i] = xi[s * 6 + i]; state[s].xi[i] = x[i]; xd[i] = x[i]; }
     pose_from_xi(x, -1.0f, state[s].pose);
+    se3_exp_d(xd, R, t);
+    for (int i = 0; i < 9; i++) state[s].Tc[i] = R[i];
+    for (int i = 0; i < 3; i++) state[s].Tc[9 + i] = t[i];
     state[s].active = 1;
     state[s].iter = 0;
 }

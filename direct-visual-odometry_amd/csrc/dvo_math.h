@@ -331,6 +331,71 @@ DVO_HD void se3_concatenate_f(const float a[6], const float b[6], float out[6])
     for (int i = 0; i < 6; i++) out[i] = (float)x[i];
 }
 
+// exp(+xi) AND exp(-xi) from one sqrt/sincos.  Bit-identical to se3_exp_d(xi) and se3_exp_d(-xi): R(-w) = R(w)^T entry
+// for entry (products of two negated factors are the same floats), w' x v' = w x v, w' x (w' x v') = -(w x (w x v)),
+// and the same A, B, so t(-xi)[i] = -v[i] + A wv[i] + B (-wwv[i]) in the same operation order.
+DVO_HD void se3_exp_pair_d(const double xi[6], double Rp[9], double tp[3], double Rm[9], double tm[3])
+{
+    const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    double c = 1.0, s = 0.0;
+    if (th < 2.220446049250313e-16) {
+        Rp[0] = 1; Rp[1] = 0; Rp[2] = 0; Rp[3] = 0; Rp[4] = 1; Rp[5] = 0; Rp[6] = 0; Rp[7] = 0; Rp[8] = 1;
+    } else {
+        c = cos(th);
+        s = sin(th);
+        const double c1 = 1.0 - c, rx = w[0] / th, ry = w[1] / th, rz = w[2] / th;
+        Rp[0] = c + c1 * rx * rx;      Rp[1] = c1 * rx * ry - s * rz; Rp[2] = c1 * rx * rz + s * ry;
+        Rp[3] = c1 * rx * ry + s * rz; Rp[4] = c + c1 * ry * ry;      Rp[5] = c1 * ry * rz - s * rx;
+        Rp[6] = c1 * rx * rz - s * ry; Rp[7] = c1 * ry * rz + s * rx; Rp[8] = c + c1 * rz * rz;
+    }
+    Rm[0] = Rp[0]; Rm[1] = Rp[3]; Rm[2] = Rp[6];
+    Rm[3] = Rp[1]; Rm[4] = Rp[4]; Rm[5] = Rp[7];
+    Rm[6] = Rp[2]; Rm[7] = Rp[5]; Rm[8] = Rp[8];
+    if ((float)th > 1e-6f) {
+        const double A = (1.0 - c) / th2, B = (th - s) / (th2 * th);
+        double wv[3], wwv[3];
+        cross3(w, v, wv);
+        cross3(w, wv, wwv);
+        for (int i = 0; i < 3; i++) {
+            tp[i] = v[i] + A * wv[i] + B * wwv[i];
+            tm[i] = -v[i] + A * wv[i] + B * (-wwv[i]);
+        }
+    } else {
+        for (int i = 0; i < 3; i++) { tp[i] = v[i]; tm[i] = -v[i]; }
+    }
+}
+
+// One pose update of Tracker::track (tracker.cpp:46-52) with exp(xi) carried from the previous iteration:
+//   xi' = float(log(exp(xi) exp(upd)));  if no NaN: Tc <- exp(xi'), pose <- float(exp(-xi')).  Returns false on NaN.
+// Tc = (R, t) of exp(xi) for the CURRENT float xi, exactly what se3_exp_d(xi) returns (so the result equals
+// se3_concatenate_f(xi, upd) followed by pose_from_xi(xi', -1) bit for bit).
+DVO_HD bool se3_update_pose(double Tc[12], const float upd[6], float xi[6], Pose& pose)
+{
+    double xu[6], Ru[9], tu[3], R[9], t[3], x[6];
+    for (int i = 0; i < 6; i++) xu[i] = upd[i];
+    se3_exp_d(xu, Ru, tu);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) R[3 * r + c] = Tc[3 * r] * Ru[c] + Tc[3 * r + 1] * Ru[3 + c] + Tc[3 * r + 2] * Ru[6 + c];
+        t[r] = Tc[3 * r] * tu[0] + Tc[3 * r + 1] * tu[1] + Tc[3 * r + 2] * tu[2] + Tc[9 + r];
+    }
+    se3_log_d(R, t, x);
+    float nxt[6];
+    bool ok = true;
+    for (int i = 0; i < 6; i++) {
+        nxt[i] = (float)x[i];
+        ok = ok && !(nxt[i] != nxt[i]);  // testXi, util.hpp:34-44
+    }
+    if (!ok) return false;
+    double xn[6], Rp[9], tp[3], Rm[9], tm[3];
+    for (int i = 0; i < 6; i++) { xi[i] = nxt[i]; xn[i] = nxt[i]; }
+    se3_exp_pair_d(xn, Rp, tp, Rm, tm);
+    for (int i = 0; i < 9; i++) { Tc[i] = Rp[i]; pose.R[i] = (float)Rm[i]; }
+    for (int i = 0; i < 3; i++) { Tc[9 + i] = tp[i]; pose.t[i] = (float)tm[i]; }
+    return true;
+}
+
 DVO_HD void pose_from_xi(const float xi[6], float sign, Pose& p)
 {
     double x[6], R[9], t[3];
@@ -401,9 +466,73 @@ DVO_HD void jacobi_eig6(double A[36], double V[36])
 
 // H: 21 upper-triangle entries row major.  Fast path LDL^T; a pivot <= 1e-12 * max diag switches to the
 // eigen pseudo-inverse with cv::solve(DECOMP_SVD)'s cut (sqrt(lambda) <= 2 FLT_EPSILON sum sqrt(lambda) dropped).
+#if defined(__HIPCC__)
+#define DVO_HD_NOINLINE __host__ __device__ __attribute__((noinline)) inline
+#else
+#define DVO_HD_NOINLINE inline
+#endif
+
+// index of (i, j), i <= j, in the 21-entry row-major upper triangle
+DVO_HD constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+DVO_HD_NOINLINE void solve6_pinv(const double H[21], const double g[6], float x[6]);
+
+// Fast path: LDL^T with every loop fully unrolled (compile-time indices only, so the factors live in registers --
+// the dynamically indexed version ran out of scratch memory and dominated k_gn_solve).  Same operation order as
+// before.  Returns through solve6_pinv when a pivot is <= 1e-12 * max diag.
 DVO_HD void solve6(const double H[21], const double g[6], float x[6])
 {
-    double A[36];
+    double maxd = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) maxd = H[tri(i, i)] > maxd ? H[tri(i, i)] : maxd;
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = 0.0f;
+    if (!(maxd > 0.0)) return;
+    double L[6][6], d[6], y[6], z[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dj = H[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * d[k];
+        ok = ok && (dj > 1e-12 * maxd);
+        d[j] = dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = H[tri(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v / dj;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double v = g[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+            y[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) y[i] /= d[i];
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            double v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) v -= L[k][i] * z[k];
+            z[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = (float)z[i];
+        return;
+    }
+    solve6_pinv(H, g, x);
+}
+
+// Rank-deficient systems: eigen pseudo-inverse (rare; kept out of line so its arrays do not burden the fast path)
+DVO_HD_NOINLINE void solve6_pinv(const double H[21], const double g[6], float x[6])
+{
+    double A[36], z[6];
     {
         int k = 0;
         for (int i = 0; i < 6; i++)
@@ -412,40 +541,6 @@ DVO_HD void solve6(const double H[21], const double g[6], float x[6])
                 A[6 * j + i] = H[k];
                 k++;
             }
-    }
-    double maxd = 0;
-    for (int i = 0; i < 6; i++) maxd = A[7 * i] > maxd ? A[7 * i] : maxd;
-    for (int i = 0; i < 6; i++) x[i] = 0.0f;
-    if (!(maxd > 0.0)) return;
-    double L[36], d[6], y[6], z[6];
-    for (int i = 0; i < 36; i++) L[i] = 0.0;
-    bool ok = true;
-    for (int j = 0; j < 6 && ok; j++) {
-        double dj = A[7 * j];
-        for (int k = 0; k < j; k++) dj -= L[6 * j + k] * L[6 * j + k] * d[k];
-        if (!(dj > 1e-12 * maxd)) { ok = false; break; }
-        d[j] = dj;
-        L[7 * j] = 1.0;
-        for (int i = j + 1; i < 6; i++) {
-            double v = A[6 * i + j];
-            for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k] * d[k];
-            L[6 * i + j] = v / dj;
-        }
-    }
-    if (ok) {
-        for (int i = 0; i < 6; i++) {
-            double v = g[i];
-            for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
-            y[i] = v;
-        }
-        for (int i = 0; i < 6; i++) y[i] /= d[i];
-        for (int i = 5; i >= 0; i--) {
-            double v = y[i];
-            for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * z[k];
-            z[i] = v;
-        }
-        for (int i = 0; i < 6; i++) x[i] = (float)z[i];
-        return;
     }
     double V[36], sv[6], sum = 0;
     jacobi_eig6(A, V);
