@@ -114,6 +114,12 @@ int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, c
     return vo->impl.odometrize_depth(gray, depth, sigma, T_rel);
 }
 
+int dvo_vo_odometrize_depth_raw(dvo_vo* vo, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
+{
+    if (!vo) return DVO_ERR_BAD_ARGUMENT;
+    return vo->impl.odometrize_depth_raw(rgb, channels, depth16, depth_scale, T_rel);
+}
+
 int dvo_vo_keyframe_count(const dvo_vo* vo) { return vo ? (int)vo->impl.hist.size() : 0; }
 
 int dvo_vo_keyframe_info(const dvo_vo* vo, int index, int* id, int* levels, int* tw, int* th, float xi[6], float rel_xi[6])
@@ -589,6 +595,44 @@ int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float*
     DVO_HIP(hipMemcpyAsync(&v, vd.p, sizeof v, hipMemcpyDeviceToHost, c.s));
     DVO_HIP(hipStreamSynchronize(c.s));
     if (valid_updates) *valid_updates = v;
+    return DVO_OK;
+}
+
+int dvo_op_ingest(int dev, const uint8_t* rgb, int channels, const uint16_t* depth16, int w, int h, float depth_scale,
+                  float sigma_valid, float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma)
+{
+    if (!rgb || !gray || w < 1 || h < 1 || (channels != 1 && channels != 3 && channels != 4)) return DVO_ERR_BAD_ARGUMENT;
+    if (depth16 && (!depth || !sigma)) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf r, d16, g, d, s;
+    DVO_TRY(r.alloc(n * channels));
+    DVO_HIP(hipMemcpyAsync(r.p, rgb, n * channels, hipMemcpyHostToDevice, c.s));
+    if (depth16) {
+        DVO_TRY(d16.alloc(n * 2));
+        DVO_HIP(hipMemcpyAsync(d16.p, depth16, n * 2, hipMemcpyHostToDevice, c.s));
+        DVO_TRY(d.alloc(n * 4)); DVO_TRY(s.alloc(n * 4));
+    }
+    DVO_TRY(g.alloc(n * 4));
+    launch_ingest(r.as<uint8_t>(), channels, depth16 ? d16.as<uint16_t>() : nullptr, (int)n, depth_scale, sigma_valid, sigma_invalid,
+                  invalidate_gray, g.as<float>(), d.as<float>(), s.as<float>(), c.s);
+    DVO_TRY(download(gray, g.p, n, c.s));
+    if (depth16) { DVO_TRY(download(depth, d.p, n, c.s)); DVO_TRY(download(sigma, s.p, n, c.s)); }
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_undistort(int dev, const float* src, int w, int h, const float K[9], const float D[5], float* dst)
+{
+    if (!src || !dst || !K || !D || w < 1 || h < 1) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf a, b;
+    DVO_TRY(upload(a, src, n, c.s));
+    DVO_TRY(b.alloc(n * 4));
+    launch_undistort(a.as<float>(), w, h, intr_of(K), D, DVO_INVALID, b.as<float>(), c.s);
+    DVO_TRY(download(dst, b.p, n, c.s));
+    DVO_HIP(hipStreamSynchronize(c.s));
     return DVO_OK;
 }
 

@@ -512,6 +512,25 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
     DVO_HIP(hipMemcpyAsync(in_gray.p, gray, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
+    return odometrize_depth_staged(T_rel);
+}
+
+int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
+{  // the same call fed with raw sensor frames: u8 gray/RGB(A) + u16 depth are converted on the device (k_ingest)
+    if (!rgb || !depth16 || !T_rel || (channels != 1 && channels != 3 && channels != 4)) { set_error("bad raw frame"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const size_t px = (size_t)w * h;
+    if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
+    DVO_HIP(hipMemcpyAsync(raw_rgb.p, rgb, px * (size_t)channels, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(raw_depth.p, depth16, px * 2, hipMemcpyHostToDevice, stream));
+    launch_ingest(raw_rgb.as<uint8_t>(), channels, raw_depth.as<uint16_t>(), (int)px, depth_scale, 0.1f, 1.0f, 1,
+                  in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
+    return odometrize_depth_staged(T_rel);
+}
+
+int VisualOdometry::odometrize_depth_staged(float T_rel[16])
+{
+    if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
     if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
     Keyframe& frame = *depth_cur;
     frame.id = ++latest_id;

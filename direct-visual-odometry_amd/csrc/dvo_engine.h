@@ -128,6 +128,9 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int init(const float K9[9], int width, int height, const dvo_config* c);
     int odometrize(const float* gray, float T_world[16], int* is_key);
     int odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16]);
+    int odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16]);
+    int odometrize_depth_staged(float T_rel[16]);  // frame already in in_gray / in_depth / in_sigma
+    DevBuf raw_rgb, raw_depth;
     int init_keyframe(const float* gray, const float* depth, const float* sigma);
     int map_propagate(Keyframe& frame, const Keyframe& ref);
     int map_update(Keyframe& obj);

@@ -109,5 +109,8 @@ void launch_propagate(const float* ref_depth, const float* ref_sigma, const floa
                       const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s);
 void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s);
 void launch_depth_update(const UpdateArgs& a, hipStream_t s);
+void launch_ingest(const uint8_t* rgb, int channels, const uint16_t* depth16, int n, float depth_scale, float sigma_valid,
+                   float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma, hipStream_t s);
+void launch_undistort(const float* src, int w, int h, const Intr& k, const float D[5], float border, float* dst, hipStream_t s);
 
 }  // namespace dvo

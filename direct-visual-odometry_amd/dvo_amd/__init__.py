@@ -71,6 +71,9 @@ EXPORTS = [
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
     "dvo_op_propagate", "dvo_op_regularize", "dvo_op_depth_update", "dvo_op_se3_exp", "dvo_op_se3_log",
     "dvo_op_se3_concatenate",
+    "dvo_png_info", "dvo_png_read", "dvo_dataset_open_tum", "dvo_dataset_open_list", "dvo_dataset_size", "dvo_dataset_entry",
+    "dvo_dataset_close", "dvo_op_ingest", "dvo_vo_odometrize_depth_raw", "dvo_op_undistort",
+    "dvo_eval_ate", "dvo_eval_rpe", "dvo_pose_inverse", "dvo_traj_write_tum",
 ]
 
 _lib = None
@@ -246,6 +249,101 @@ def mapper_update(hist_gray, hist_xi, obj_gray, obj_xi, obj_rel_xi, obj_id, K, r
     return d, s, a, v.value
 
 
+# ------------------------------------------------------------------ Core::Loader (dataset front-end) and evaluation
+def imread(path):
+    """cv::imread(path, IMREAD_UNCHANGED) for PNGs: uint8 / uint16 array [H, W] or [H, W, C] in file channel order (RGB)."""
+    w = C.c_int(); h = C.c_int(); ch = C.c_int(); bd = C.c_int()
+    _check(lib().dvo_png_info(path.encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(bd)))
+    shape = (h.value, w.value) if ch.value == 1 else (h.value, w.value, ch.value)
+    out = np.zeros(shape, np.uint8 if bd.value == 8 else np.uint16)
+    _check(lib().dvo_png_read(path.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+    return out
+
+
+class Dataset:
+    """TUM RGB-D directory or one of the reference's list files (include/core/loader.hpp:28-52,77-105)."""
+
+    def __init__(self, directory, list_file=None, tum=False, max_dt=0.02):
+        self._p = C.c_void_p()
+        if tum:
+            _check(lib().dvo_dataset_open_tum(directory.encode(), C.c_double(max_dt), C.byref(self._p)))
+        else:
+            _check(lib().dvo_dataset_open_list(directory.encode(), list_file.encode() if list_file else None, C.byref(self._p)))
+
+    def __len__(self):
+        return lib().dvo_dataset_size(self._p)
+
+    def entry(self, i):
+        t = C.c_double(); a = C.create_string_buffer(1024); b = C.create_string_buffer(1024); gt = np.zeros(7, np.float32)
+        _check(lib().dvo_dataset_entry(self._p, i, C.byref(t), a, b, 1024, fp(gt)))
+        return dict(timestamp=t.value, rgb=a.value.decode(), depth=b.value.decode(), gt=gt)
+
+    def close(self):
+        if self._p:
+            lib().dvo_dataset_close(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ingest(rgb, depth16=None, depth_scale=1.0 / 5000.0, sigma_valid=0.1, sigma_invalid=1.0, invalidate_gray=True, dev=0):
+    """k_ingest: raw u8 gray/RGB(A) (+ u16 depth) -> float gray [0,1] (+ depth [m], sigma)."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    ch = 1 if rgb.ndim == 2 else rgb.shape[2]
+    gray = np.zeros((h, w), np.float32)
+    if depth16 is None:
+        _check(lib().dvo_op_ingest(dev, rgb.ctypes.data_as(C.c_void_p), ch, None, w, h, C.c_float(depth_scale), C.c_float(sigma_valid),
+                                   C.c_float(sigma_invalid), 0, fp(gray), None, None))
+        return gray
+    d16 = np.ascontiguousarray(depth16, np.uint16)
+    depth = np.zeros((h, w), np.float32); sigma = np.zeros((h, w), np.float32)
+    _check(lib().dvo_op_ingest(dev, rgb.ctypes.data_as(C.c_void_p), ch, d16.ctypes.data_as(C.c_void_p), w, h, C.c_float(depth_scale),
+                               C.c_float(sigma_valid), C.c_float(sigma_invalid), 1 if invalidate_gray else 0, fp(gray), fp(depth), fp(sigma)))
+    return gray, depth, sigma
+
+
+def undistort(src, K, D, dev=0):
+    """Loader::getNormalizedUndistortedImages (src/core/loader.cpp:15-42)."""
+    src = f32(src); K = f32(K).reshape(9); D = f32(D).reshape(5)
+    h, w = src.shape
+    out = np.zeros_like(src)
+    _check(lib().dvo_op_undistort(dev, fp(src), w, h, fp(K), fp(D), fp(out)))
+    return out
+
+
+def ate(est_xyz, gt_xyz, with_scale=False):
+    """Absolute trajectory error (RMSE after Horn alignment).  Returns (rmse, R, t, scale)."""
+    e = f32(est_xyz).reshape(-1, 3); g = f32(gt_xyz).reshape(-1, 3)
+    rm = C.c_double(); R = np.zeros(9); t = np.zeros(3); s = C.c_double()
+    _check(lib().dvo_eval_ate(e.shape[0], fp(e), fp(g), 1 if with_scale else 0, C.byref(rm), R.ctypes.data_as(C.POINTER(C.c_double)),
+                              t.ctypes.data_as(C.POINTER(C.c_double)), C.byref(s)))
+    return rm.value, R.reshape(3, 3), t, s.value
+
+
+def rpe(est_T, gt_T, delta=1):
+    e = f32(est_T).reshape(-1, 16); g = f32(gt_T).reshape(-1, 16)
+    a = C.c_double(); b = C.c_double()
+    _check(lib().dvo_eval_rpe(e.shape[0], fp(e), fp(g), delta, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def pose_inverse(T):
+    T = f32(T).reshape(16); o = np.zeros(16, np.float32)
+    _check(lib().dvo_pose_inverse(fp(T), fp(o)))
+    return o.reshape(4, 4)
+
+
+def write_tum_trajectory(path, T, timestamps=None):
+    T = f32(T).reshape(-1, 16)
+    ts = np.ascontiguousarray(timestamps, np.float64) if timestamps is not None else None
+    _check(lib().dvo_traj_write_tum(path.encode(), T.shape[0], ts.ctypes.data_as(C.POINTER(C.c_double)) if ts is not None else None, fp(T)))
+
+
 # ------------------------------------------------------------------ System::VisualOdometry
 class VisualOdometry:
     """System::VisualOdometry (include/system/system.hpp:12-104)."""
@@ -283,6 +381,14 @@ class VisualOdometry:
     def odometrizeUsingDepth(self, gray, depth, sigma):
         g = f32(gray); d = f32(depth); s = f32(sigma); T = np.zeros(16, np.float32)
         _check(lib().dvo_vo_odometrize_depth(self._p, fp(g), fp(d), fp(s), fp(T)))
+        return T.reshape(4, 4)
+
+    def odometrizeUsingDepthRaw(self, rgb_u8, depth_u16, depth_scale=1.0 / 5000.0):
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8); d16 = np.ascontiguousarray(depth_u16, np.uint16)
+        ch = 1 if rgb.ndim == 2 else rgb.shape[2]
+        T = np.zeros(16, np.float32)
+        _check(lib().dvo_vo_odometrize_depth_raw(self._p, rgb.ctypes.data_as(C.c_void_p), ch, d16.ctypes.data_as(C.c_void_p),
+                                                 C.c_float(depth_scale), fp(T)))
         return T.reshape(4, 4)
 
     def keyframeCount(self):

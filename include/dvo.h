@@ -193,6 +193,48 @@ int dvo_op_se3_exp(int dev, const float xi[6], float T[16]);
 int dvo_op_se3_log(int dev, const float T[16], float xi[6]);
 int dvo_op_se3_concatenate(int dev, const float a[6], const float b[6], float out[6]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dataset front-end: what src/core/loader.cpp + include/core/loader.hpp do with OpenCV.
+ * ------------------------------------------------------------------------------------------------ */
+/* PNG reader (cv::imread(IMREAD_UNCHANGED), loader.cpp:61-73,149-160): non-interlaced 8/16-bit gray, gray+alpha, RGB, RGBA.
+ * pixels: row-major interleaved channels in FILE order (R,G,B[,A]); 16-bit samples as host-endian uint16. */
+int dvo_png_info(const char* path, int* width, int* height, int* channels, int* bit_depth);
+int dvo_png_read(const char* path, void* pixels, size_t capacity_bytes);
+typedef struct dvo_dataset dvo_dataset;
+/* TUM RGB-D directory: rgb.txt + depth.txt associated by nearest timestamp (|dt| <= max_dt, default 0.02 s),
+ * optional groundtruth.txt (tx ty tz qx qy qz qw). */
+int dvo_dataset_open_tum(const char* dir, double max_dt, dvo_dataset** out);
+/* The reference's list files (include/core/loader.hpp:38-47,87-98): "file" or "rgb depth" per line; NULL = dir/info.txt */
+int dvo_dataset_open_list(const char* dir, const char* list_file, dvo_dataset** out);
+int dvo_dataset_size(const dvo_dataset* d);
+int dvo_dataset_entry(const dvo_dataset* d, int i, double* timestamp, char* rgb_path, char* depth_path, int path_capacity,
+                      float gt_pose7[7]);
+int dvo_dataset_close(dvo_dataset* d);
+/* Device-side conversion of raw sensor frames (k_ingest): gray = BGR2GRAY(u8)/255 (loader.cpp:55-60,137-147), depth =
+ * u16 * depth_scale (1/5000), sigma = sigma_valid where depth > 0 else sigma_invalid, gray = INVALID where depth == 0 when
+ * invalidate_gray (what Transform::mapDepthtoGray leaves, src/core/transform.cpp:60-76).  depth16 may be NULL (gray only). */
+int dvo_op_ingest(int dev, const uint8_t* rgb, int channels, const uint16_t* depth16, int w, int h, float depth_scale,
+                  float sigma_valid, float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma);
+/* odometrizeUsingDepth fed with raw frames (u8 gray/RGB/RGBA + u16 depth): converted on the device, 1.5 instead of 3.7 MB/frame */
+int dvo_vo_odometrize_depth_raw(dvo_vo* vo, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale,
+                                float T_rel[16]);
+/* Loader::getNormalizedUndistortedImages (loader.cpp:15-42): radial-tangential undistortion D = (k1,k2,p1,p2,k3), nearest
+ * remap, INVALID border. */
+int dvo_op_undistort(int dev, const float* src, int w, int h, const float K[9], const float D[5], float* dst);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trajectory evaluation / export.  Host side, double precision.
+ * ------------------------------------------------------------------------------------------------ */
+/* ATE: RMSE of |gt_i - (s R est_i + t)| after the optimal rigid (with_scale: similarity) alignment (Horn). xyz: [n][3] */
+int dvo_eval_ate(int n, const float* est_xyz, const float* gt_xyz, int with_scale, double* rmse, double R_out[9],
+                 double t_out[3], double* scale_out);
+/* RPE over `delta` frames: RMSE of the translational part [m] and of the rotation angle [rad]; poses [n][16] row major */
+int dvo_eval_rpe(int n, const float* est_T, const float* gt_T, int delta, double* trans_rmse, double* rot_rmse);
+/* the correct rigid inverse (Convert::inversePose, src/core/convert.cpp:31-39, is wrong in the reference) */
+int dvo_pose_inverse(const float T[16], float out[16]);
+/* "timestamp tx ty tz qx qy qz qw" per line; timestamps may be NULL (frame index is written) */
+int dvo_traj_write_tum(const char* path, int n, const double* timestamps, const float* T);
+
 #ifdef __cplusplus
 }
 #endif

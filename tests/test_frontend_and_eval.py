@@ -1,0 +1,209 @@
+"""Tests of the rows SURVEY.md §8f marks "next": dataset front-end (PNG reader, TUM / list datasets, device ingest,
+undistortion) and trajectory evaluation (ATE, RPE, TUM export).  The reference pins nothing here either; the
+checkers are PIL (PNG), numpy restatements of the integer/byte arithmetic (ingest: bit exact) and of Umeyama's method."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import dvo_amd as dvo
+
+
+# ---------------------------------------------------------------- PNG reader (CPU)
+@pytest.mark.parametrize("mode,dtype", [("L", np.uint8), ("RGB", np.uint8), ("RGBA", np.uint8), ("I;16", np.uint16)])
+def test_png_reader_matches_pil(tmp_path, mode, dtype):
+    rng = np.random.RandomState(1)
+    h, w = 37, 53
+    if mode == "L":
+        a = (rng.uniform(size=(h, w)) * 255).astype(np.uint8)
+    elif mode == "I;16":
+        a = (rng.uniform(size=(h, w)) * 65535).astype(np.uint16)
+    else:
+        a = (rng.uniform(size=(h, w, len(mode))) * 255).astype(np.uint8)
+    # smooth gradients make PIL's encoder pick different scan-line filters (sub / up / average / paeth)
+    a[10:20] = np.arange(w, dtype=dtype)[None, :, None] if a.ndim == 3 else np.arange(w, dtype=dtype)[None, :]
+    p = str(tmp_path / "t.png")
+    Image.fromarray(a, mode=mode).save(p)
+    got = dvo.imread(p)
+    assert got.dtype == dtype and got.shape == a.shape
+    np.testing.assert_array_equal(got, a)
+
+
+def test_png_reader_errors_are_status_codes(tmp_path):
+    with pytest.raises(dvo.DvoError):
+        dvo.imread(str(tmp_path / "missing.png"))
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png at all, definitely not one, no header here")
+    with pytest.raises(dvo.DvoError):
+        dvo.imread(str(bad))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/data/logicool0/0000.png"), reason="reference data not mounted")
+def test_png_reader_on_the_reference_frames():
+    for p in ("/root/reference/data/logicool0/0000.png", "/root/reference/data/KINECT_50MM/depth01.png"):
+        np.testing.assert_array_equal(dvo.imread(p), np.asarray(Image.open(p)))
+
+
+# ---------------------------------------------------------------- datasets (CPU)
+def test_tum_association_and_groundtruth(tmp_path):
+    d = tmp_path / "seq"
+    d.mkdir()
+    (d / "rgb.txt").write_text("# color images\n# file\n# timestamp filename\n1.00 rgb/1.00.png\n1.10 rgb/1.10.png\n1.20 rgb/1.20.png\n1.50 rgb/1.50.png\n")
+    (d / "depth.txt").write_text("# depth\n0.995 depth/0.995.png\n1.105 depth/1.105.png\n1.26 depth/1.26.png\n")
+    (d / "groundtruth.txt").write_text("# gt\n1.001 1 2 3 0 0 0 1\n1.099 4 5 6 0 0 0 1\n")
+    ds = dvo.Dataset(str(d), tum=True, max_dt=0.02)
+    assert len(ds) == 2                                   # 1.20 (dt 0.06) and 1.50 have no depth within 20 ms
+    e0, e1 = ds.entry(0), ds.entry(1)
+    assert e0["rgb"].endswith("rgb/1.00.png") and e0["depth"].endswith("depth/0.995.png")
+    assert e1["rgb"].endswith("rgb/1.10.png") and e1["depth"].endswith("depth/1.105.png")
+    np.testing.assert_array_equal(e0["gt"], [1, 2, 3, 0, 0, 0, 1])
+    np.testing.assert_array_equal(e1["gt"], [4, 5, 6, 0, 0, 0, 1])
+    assert len(dvo.Dataset(str(d), tum=True, max_dt=0.1)) == 3
+    with pytest.raises(dvo.DvoError):
+        dvo.Dataset(str(tmp_path / "nope"), tum=True)
+
+
+def test_reference_list_files(tmp_path):
+    d = tmp_path / "k"
+    d.mkdir()
+    (d / "info.txt").write_text("rgb01.png depth01.png\nrgb02.png depth02.png\n")   # data/KINECT_50MM/info.txt format
+    ds = dvo.Dataset(str(d))
+    assert len(ds) == 2 and ds.entry(1)["depth"].endswith("k/depth02.png")
+    (d / "mono.txt").write_text("0000.png\n0001.png\n0002.png\n")                    # data/logicool0/info.txt format
+    ds = dvo.Dataset(str(d), list_file=str(d / "mono.txt"))
+    assert len(ds) == 3 and ds.entry(2)["rgb"].endswith("0002.png") and ds.entry(2)["depth"] == ""
+    with pytest.raises(dvo.DvoError):                    # the reference abort()s (include/core/loader.hpp:33-36)
+        dvo.Dataset(str(d), list_file=str(d / "missing.txt"))
+
+
+# ---------------------------------------------------------------- evaluation (CPU)
+def _umeyama_np(est, gt):
+    ce, cg = est.mean(0), gt.mean(0)
+    H = (est - ce).T @ (gt - cg)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    t = cg - R @ ce
+    return R, t
+
+
+def test_ate_matches_svd_alignment():
+    rng = np.random.RandomState(3)
+    gt = np.cumsum(rng.normal(0, 0.05, (200, 3)), 0)
+    ang = 0.7
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    est = (gt - [1, 2, 3]) @ Rz + rng.normal(0, 0.01, gt.shape)   # rotated, shifted, noisy copy
+    rm, R, t, s = dvo.ate(est, gt)
+    e32, g32 = est.astype(np.float32).astype(np.float64), gt.astype(np.float32).astype(np.float64)
+    Rn, tn = _umeyama_np(e32, g32)
+    np.testing.assert_allclose(R, Rn, atol=1e-6)
+    np.testing.assert_allclose(t, tn, atol=1e-6)
+    exp = np.sqrt(np.mean(np.sum((g32 - (e32 @ Rn.T + tn)) ** 2, 1)))
+    assert abs(rm - exp) < 1e-7 and 0.01 < rm < 0.03 and s == 1.0
+    rm2, _, _, s2 = dvo.ate(est * 2.0, gt, with_scale=True)
+    assert abs(s2 - 0.5) < 5e-3 and abs(rm2 - rm) < 2e-3
+    assert dvo.ate(gt, gt)[0] < 1e-6
+    with pytest.raises(dvo.DvoError):
+        dvo.ate(gt[:2], gt[:2])
+
+
+def test_rpe_pose_inverse_and_tum_export(tmp_path):
+    from dvo_amd.synth import se3_exp_np, trajectory
+    gt = np.array(trajectory(30, seed=5))
+    assert max(dvo.rpe(gt, gt)) < 1e-3                    # float32 poses in, acos near 1 is noisy: just "small"
+    # an estimate that drifts by a constant 1 mm / 0.001 rad per frame
+    drift = se3_exp_np([0.001, 0, 0, 0, 0, 0.001])
+    est = [np.eye(4)]
+    for i in range(1, 30):
+        est.append(est[-1] @ (np.linalg.inv(gt[i - 1]) @ gt[i]) @ drift)
+    tr, rr = dvo.rpe(np.array(est), gt, delta=1)
+    assert abs(tr - 0.001) < 5e-5 and abs(rr - 0.001) < 5e-4
+    T = gt[7].astype(np.float32)
+    np.testing.assert_allclose(dvo.pose_inverse(T) @ T, np.eye(4), atol=1e-6)   # unlike Convert::inversePose (convert.cpp:31-39)
+    p = str(tmp_path / "traj.txt")
+    dvo.write_tum_trajectory(p, gt, timestamps=np.arange(30) * 0.1)
+    rows = [l.split() for l in open(p) if not l.startswith("#")]
+    assert len(rows) == 30 and len(rows[0]) == 8
+    q = np.array(rows[12][4:], float)
+    xyz = np.array(rows[12][1:4], float)
+    np.testing.assert_allclose(xyz, gt[12][:3, 3], atol=1e-6)
+    assert abs(np.linalg.norm(q) - 1) < 1e-6
+    qx, qy, qz, qw = q
+    Rq = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                   [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                   [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    np.testing.assert_allclose(Rq, gt[12][:3, :3], atol=1e-6)
+
+
+# ---------------------------------------------------------------- device ingest / undistort (GPU)
+def _ingest_np(rgb, d16, scale=1.0 / 5000.0):
+    if rgb.ndim == 2:
+        g8 = rgb.astype(np.uint32)
+    else:
+        r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
+        g8 = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+    gray = g8.astype(np.float32) * np.float32(1.0 / 255.0)
+    depth = d16.astype(np.float32) * np.float32(scale)
+    sigma = np.where(d16 > 0, np.float32(0.1), np.float32(1.0)).astype(np.float32)
+    gray = np.where(d16 == 0, np.float32(-2.0), gray).astype(np.float32)
+    return gray, depth, sigma
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_ingest_bit_exact(channels):
+    rng = np.random.RandomState(7)
+    h, w = 61, 97
+    rgb = (rng.uniform(size=(h, w) if channels == 1 else (h, w, channels)) * 255).astype(np.uint8)
+    d16 = (rng.uniform(size=(h, w)) * 20000).astype(np.uint16)
+    d16[rng.uniform(size=(h, w)) < 0.1] = 0
+    g, d, s = dvo.ingest(rgb, d16)
+    eg, ed, es = _ingest_np(rgb, d16)
+    np.testing.assert_array_equal(g, eg)
+    np.testing.assert_array_equal(d, ed)
+    np.testing.assert_array_equal(s, es)
+    g2 = dvo.ingest(rgb)                               # gray only
+    assert (g2 >= 0).all() and g2.max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_undistort_nearest_remap():
+    rng = np.random.RandomState(8)
+    h, w = 120, 160
+    img = rng.uniform(0, 1, (h, w)).astype(np.float32)
+    K = np.array([[195, 0, 94.5], [0, 199, 55], [0, 0, 1]], np.float32)        # loader.cpp:17 scaled by 1/4
+    D = np.array([-0.0462, 0.152, -0.00429, 0.0117, -0.0725], np.float32)      # loader.cpp:18
+    got = dvo.undistort(img, K, D)
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    x = (u - K[0, 2]) / K[0, 0]
+    y = (v - K[1, 2]) / K[1, 1]
+    r2 = x * x + y * y
+    rad = 1 + r2 * (D[0] + r2 * (D[1] + r2 * D[4]))
+    xd = x * rad + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * rad + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
+    mx = np.rint((xd * K[0, 0] + K[0, 2]).astype(np.float32)).astype(int)
+    my = np.rint((yd * K[1, 1] + K[1, 2]).astype(np.float32)).astype(int)
+    ok = (mx >= 0) & (mx < w) & (my >= 0) & (my < h)
+    exp = np.full((h, w), -2.0, np.float32)
+    exp[ok] = img[my[ok], mx[ok]]
+    assert (got == exp).mean() > 0.999                    # ties of rint at .5 may differ in the last double bit
+    np.testing.assert_array_equal(dvo.undistort(img, K, np.zeros(5, np.float32)), img)
+
+
+@pytest.mark.gpu
+def test_odometrize_raw_equals_float_path():
+    from util import K640, frames
+    g, d, s, _ = frames(3, sigma=0.1)
+    vo_a = dvo.VisualOdometry(K640, 640, 480)
+    vo_b = dvo.VisualOdometry(K640, 640, 480)
+    for i in range(3):
+        rgb = np.clip(np.rint(g[i] * 255), 0, 255).astype(np.uint8)
+        d16 = np.clip(np.rint(d[i] * 5000), 0, 65535).astype(np.uint16)
+        d16[5:9, 7:30] = 0                                # holes: gray INVALID, sigma 1 (transform.cpp:60-76)
+        fg, fd, fs = dvo.ingest(rgb, d16)
+        Ta = vo_a.odometrizeUsingDepth(fg, fd, fs)
+        Tb = vo_b.odometrizeUsingDepthRaw(rgb, d16)
+        np.testing.assert_array_equal(Ta, Tb)
+    vo_a.close()
+    vo_b.close()
