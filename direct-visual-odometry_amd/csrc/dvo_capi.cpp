@@ -582,6 +582,7 @@ int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float*
     a.ref_depth = rd.as<float>(); a.ref_sigma = rs.as<float>(); a.ref_age = ra.as<float>();
     a.obj_gray = og.as<float>(); a.ages = ages.as<AgeEntry>();
     a.n_hist = n_hist; a.w = w; a.h = h; a.crop = cf.crop_enable; a.obj_id = obj_id; a.seed = cf.rng_seed;
+    a.clamp_age = 0;
     a.k = intr_of(K);
     memcpy(a.K9, K, sizeof a.K9);
     pose_from_xi(obj_rel_xi, 1.0f, a.rel_pose);
@@ -618,6 +619,21 @@ int dvo_op_ingest(int dev, const uint8_t* rgb, int channels, const uint16_t* dep
                   invalidate_gray, g.as<float>(), d.as<float>(), s.as<float>(), c.s);
     DVO_TRY(download(gray, g.p, n, c.s));
     if (depth16) { DVO_TRY(download(depth, d.p, n, c.s)); DVO_TRY(download(sigma, s.p, n, c.s)); }
+    DVO_HIP(hipStreamSynchronize(c.s));
+    return DVO_OK;
+}
+
+int dvo_op_visualize(int dev, int mode, const float* a, const float* b, int w, int h, uint8_t* rgb)
+{
+    if (!a || !rgb || w < 1 || h < 1 || mode < 0 || mode > 4) return DVO_ERR_BAD_ARGUMENT;
+    OpCtx c; DVO_TRY(c.open(dev));
+    const size_t n = (size_t)w * h;
+    DevBuf da, db, out;
+    DVO_TRY(upload(da, a, n, c.s));
+    if (b) DVO_TRY(upload(db, b, n, c.s));
+    DVO_TRY(out.alloc(n * 3));
+    launch_visualize(mode, da.as<float>(), b ? db.as<float>() : nullptr, (int)n, out.as<uint8_t>(), c.s);
+    DVO_HIP(hipMemcpyAsync(rgb, out.p, n * 3, hipMemcpyDeviceToHost, c.s));
     DVO_HIP(hipStreamSynchronize(c.s));
     return DVO_OK;
 }

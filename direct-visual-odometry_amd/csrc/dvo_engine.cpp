@@ -426,6 +426,7 @@ int VisualOdometry::map_update(Keyframe& obj)
     a.obj_gray = obj.fs.gray[T];
     a.ages = ages.as<AgeEntry>();
     a.n_hist = n_hist; a.w = tw; a.h = th; a.crop = cfg.crop_enable; a.obj_id = obj.id;
+    a.clamp_age = history_limit > 0 ? 1 : 0;
     a.seed = cfg.rng_seed;
     a.k = geoM.k[T];
     memcpy(a.K9, geoM.K9[T], sizeof a.K9);
@@ -495,6 +496,10 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
         DVO_TRY(map_propagate(frame, ref));
         hist.push_back(std::move(scratch));
         if (is_key) *is_key = 1;
+        if (history_limit > 0 && (int)hist.size() > history_limit) {  // bounded store: drop the oldest keyframes
+            DVO_HIP(hipStreamSynchronize(stream));                    // their buffers may still be read by queued kernels
+            hist.erase(hist.begin(), hist.begin() + ((int)hist.size() - history_limit));
+        }
     } else {
         DVO_TRY(map_update(frame));
     }

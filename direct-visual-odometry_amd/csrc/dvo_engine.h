@@ -121,6 +121,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     DevBuf tmp_a, tmp_b, tmp_c, owner, ages, valid_dev;
     std::vector<float> init_depth, init_sigma;
     int latest_id = -1;                                // Frame::latest_id, frame.cpp:5
+    int history_limit = 0;                             // 0 = keep every keyframe (the reference); N = keep the newest N
     int last_id = -1, last_valid_updates = 0;
     float last_xi[6] = {0}, last_rel[6] = {0};
     dvo_track_log last_log;

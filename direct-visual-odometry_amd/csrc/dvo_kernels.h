@@ -78,6 +78,7 @@ struct UpdateArgs {
     const float* obj_gray;
     const AgeEntry* ages;    // [n_hist], index = history index (oldest first)
     int n_hist, w, h, crop, obj_id;
+    int clamp_age;           // bounded history: a pixel born in a dropped keyframe searches the oldest retained one
     uint32_t seed;
     Intr k;
     float K9[9];
@@ -111,6 +112,7 @@ void launch_regularize(const float* depth, const float* sigma, int w, int h, flo
 void launch_depth_update(const UpdateArgs& a, hipStream_t s);
 void launch_ingest(const uint8_t* rgb, int channels, const uint16_t* depth16, int n, float depth_scale, float sigma_valid,
                    float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma, hipStream_t s);
+void launch_visualize(int mode, const float* a, const float* b, int n, uint8_t* rgb, hipStream_t s);
 void launch_undistort(const float* src, int w, int h, const Intr& k, const float D[5], float border, float* dst, hipStream_t s);
 
 }  // namespace dvo

@@ -781,7 +781,8 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
     if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
     const int age = (int)a.ref_age[i];                                 // mapper.cpp:99
-    const int bi = a.n_hist - 1 - age;                                 // frame.hpp:176
+    int bi = a.n_hist - 1 - age;                                       // frame.hpp:176
+    if (bi < 0 && a.clamp_age) bi = 0;
     if (bi < 0 || bi >= a.n_hist) return;
     const AgeEntry& born = a.ages[bi];
     const float depth = d - a.rel_tz;                                  // mapper.cpp:104
@@ -925,8 +926,58 @@ __global__ void __launch_bounds__(256) k_undistort(const float* __restrict__ src
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_visualize: the false-colour views of src/core/draw.cpp:7-100 as plain RGB bytes (no GUI).
+//   mode 0 gray      (Draw::visualizeGray: value*255, INVALID pixels blue)
+//   mode 1 depth     (Draw::visualizeDepth(depth, sigma): hue from depth, value from sigma; b may be null -> full value)
+//   mode 2 sigma     (Draw::visualizeSigma: 255 - 500 sigma)
+//   mode 3 age       (Draw::visualizeAge: 10 * age)
+//   mode 4 gradient  (Draw::visualizeGradient: green positive, red negative, INVALID blue)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned char sat_u8(float v)
+{
+    v = rintf(v);
+    return (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+}
+
+__global__ void __launch_bounds__(256) k_visualize(int mode, const float* __restrict__ a, const float* __restrict__ b, int n, uint8_t* __restrict__ rgb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = a[i];
+    unsigned char R = 0, G = 0, B = 0;
+    if (mode == 0) {
+        R = G = B = sat_u8(v * 255.0f);
+        if (!is_valid(v)) B = 255;
+    } else if (mode == 1) {
+        if (!(v < kEpsilon)) {
+            const float hue = fminf(fmaxf((v - 0.70f) * 70.0f, 0.0f), 180.0f);  // OpenCV 8-bit hue: degrees / 2
+            const float val = b ? (float)(unsigned char)(-500.0f * fminf(b[i], 0.5f) + 255.0f) / 255.0f : 1.0f;
+            const float hh = (float)(unsigned char)hue * 2.0f / 60.0f;
+            const float c = val, x = c * (1.0f - fabsf(fmodf(hh, 2.0f) - 1.0f));
+            float r = 0, g = 0, bl = 0;
+            if (hh < 1) { r = c; g = x; } else if (hh < 2) { r = x; g = c; } else if (hh < 3) { g = c; bl = x; }
+            else if (hh < 4) { g = x; bl = c; } else if (hh < 5) { r = x; bl = c; } else { r = c; bl = x; }
+            R = sat_u8(r * 255.0f); G = sat_u8(g * 255.0f); B = sat_u8(bl * 255.0f);
+        }
+    } else if (mode == 2) {
+        R = G = B = sat_u8(v * -500.0f + 255.0f);
+    } else if (mode == 3) {
+        R = G = B = sat_u8(v * 10.0f);
+    } else {
+        if (is_invalid(v)) B = 255;
+        else { G = (unsigned char)(255.0f * fminf(fmaxf(v, 0.0f), 1.0f)); R = (unsigned char)(255.0f * fminf(fmaxf(-v, 0.0f), 1.0f)); }
+    }
+    rgb[3 * (size_t)i] = R; rgb[3 * (size_t)i + 1] = G; rgb[3 * (size_t)i + 2] = B;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------------
+void launch_visualize(int mode, const float* a, const float* b, int n, uint8_t* rgb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_visualize, dim3((n + 255) / 256), dim3(256), 0, s, mode, a, b, n, rgb);
+}
+
 void launch_ingest(const uint8_t* rgb, int channels, const uint16_t* depth16, int n, float depth_scale, float sigma_valid,
                    float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma, hipStream_t s)
 {

@@ -74,6 +74,7 @@ EXPORTS = [
     "dvo_png_info", "dvo_png_read", "dvo_dataset_open_tum", "dvo_dataset_open_list", "dvo_dataset_size", "dvo_dataset_entry",
     "dvo_dataset_close", "dvo_op_ingest", "dvo_vo_odometrize_depth_raw", "dvo_op_undistort",
     "dvo_eval_ate", "dvo_eval_rpe", "dvo_pose_inverse", "dvo_traj_write_tum",
+    "dvo_vo_save", "dvo_vo_load", "dvo_vo_set_history_limit", "dvo_op_visualize", "dvo_ppm_write",
 ]
 
 _lib = None
@@ -316,6 +317,23 @@ def undistort(src, K, D, dev=0):
     return out
 
 
+VIS_GRAY, VIS_DEPTH, VIS_SIGMA, VIS_AGE, VIS_GRADIENT = range(5)
+
+
+def visualize(mode, a, b=None, dev=0):
+    """Draw::visualize{Gray,Depth,Sigma,Age,Gradient} (src/core/draw.cpp:7-100) -> uint8 RGB [H, W, 3]."""
+    a = f32(a); h, w = a.shape
+    bb = f32(b) if b is not None else None
+    out = np.zeros((h, w, 3), np.uint8)
+    _check(lib().dvo_op_visualize(dev, int(mode), fp(a), fp(bb) if bb is not None else None, w, h, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def write_ppm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _check(lib().dvo_ppm_write(path.encode(), rgb.ctypes.data_as(C.c_void_p), rgb.shape[1], rgb.shape[0]))
+
+
 def ate(est_xyz, gt_xyz, with_scale=False):
     """Absolute trajectory error (RMSE after Horn alignment).  Returns (rmse, R, t, scale)."""
     e = f32(est_xyz).reshape(-1, 3); g = f32(gt_xyz).reshape(-1, 3)
@@ -390,6 +408,15 @@ class VisualOdometry:
         _check(lib().dvo_vo_odometrize_depth_raw(self._p, rgb.ctypes.data_as(C.c_void_p), ch, d16.ctypes.data_as(C.c_void_p),
                                                  C.c_float(depth_scale), fp(T)))
         return T.reshape(4, 4)
+
+    def save(self, path):
+        _check(lib().dvo_vo_save(self._p, path.encode()))
+
+    def load(self, path):
+        _check(lib().dvo_vo_load(self._p, path.encode()))
+
+    def setHistoryLimit(self, n):
+        _check(lib().dvo_vo_set_history_limit(self._p, int(n)))
 
     def keyframeCount(self):
         return lib().dvo_vo_keyframe_count(self._p)

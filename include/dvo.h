@@ -223,6 +223,21 @@ int dvo_vo_odometrize_depth_raw(dvo_vo* vo, const uint8_t* rgb, int channels, co
 int dvo_op_undistort(int dev, const float* src, int w, int h, const float K[9], const float D[5], float* dst);
 
 /* ------------------------------------------------------------------------------------------------
+ * Keyframe store / checkpoint and debug views (row 4).
+ * ------------------------------------------------------------------------------------------------ */
+/* Dump / restore the whole FrameHistory (include/system/frame.hpp:146-188): per keyframe id, poses, the gray pyramid and the
+ * top-level depth / sigma / age.  dvo_vo_load needs a handle created with the same K and frame size; it replaces the history. */
+int dvo_vo_save(const dvo_vo* vo, const char* path);
+int dvo_vo_load(dvo_vo* vo, const char* path);
+/* 0 = keep every keyframe (the reference); N > 0 = keep the newest N (a pixel born in a dropped keyframe then matches
+ * against the oldest retained one -- the reference's commented-out `age = std::min(age, 2)`, src/map/mapper.cpp:100). */
+int dvo_vo_set_history_limit(dvo_vo* vo, int max_keyframes);
+/* False-colour views of src/core/draw.cpp:7-100 as RGB bytes [h][w][3]: mode 0 gray (INVALID blue), 1 depth (hue) with
+ * optional sigma (value) in b, 2 sigma, 3 age, 4 gradient.  No GUI: write them with dvo_ppm_write. */
+int dvo_op_visualize(int dev, int mode, const float* a, const float* b, int w, int h, uint8_t* rgb);
+int dvo_ppm_write(const char* path, const uint8_t* rgb, int w, int h);
+
+/* ------------------------------------------------------------------------------------------------
  * Trajectory evaluation / export.  Host side, double precision.
  * ------------------------------------------------------------------------------------------------ */
 /* ATE: RMSE of |gt_i - (s R est_i + t)| after the optimal rigid (with_scale: similarity) alignment (Horn). xyz: [n][3] */
