@@ -170,6 +170,7 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
 // ------------------------------------------------------------------------------------------------ tracker
 Tracker::~Tracker()
 {
+    if (h_state) (void)hipHostFree(h_state);
     for (auto& e : ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -267,8 +268,8 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     // Small batches: every few iterations ask the device whether anything is still active, so a converged
     // level does not pay for its remaining (empty) launches.  Big batches run the fixed schedule sync-free.
     const bool poll = (cfg.fixed_iterations <= 0) && n_seq <= 8;
-    std::vector<SeqState> host_state;
-    if (poll) host_state.resize(n_seq);
+    if (poll && !h_state) DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(SeqState) * (size_t)n_seq, hipHostMallocDefault));
+    SeqState* host_state = h_state;  // pinned: the read-back is one async copy + one stream sync, no staging
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
         for (int it = 0; it < max_it; it++) {          // tracker.cpp:42
             const int first = (it == 0) ? 1 : 0;
@@ -299,7 +300,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
             sa.ignore_active = first;
             launch_gn_solve(sa, n_seq, s);
             if (poll && it + 1 < max_it) {
-                DVO_HIP(hipMemcpyAsync(host_state.data(), state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));
+                DVO_HIP(hipMemcpyAsync(host_state, state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));
                 DVO_HIP(hipStreamSynchronize(s));
                 bool any = false;
                 for (int q = 0; q < n_seq; q++) any = any || host_state[q].active != 0;

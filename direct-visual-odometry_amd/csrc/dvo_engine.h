@@ -81,6 +81,7 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     DevBuf state, partials, log, counters, xi_out, T_out;
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
+    SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
     void launch_gn(const GnArgs& a, int level, hipStream_t s) const;
     // profiling (cfg.profile)
