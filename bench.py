@@ -60,11 +60,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libdvo has no CPU fallback)")
+    # DVO_BENCH_REHEARSE=1: multi-rank control flow on ONE GPU (every rank on cuda:0, gloo collectives on CPU tensors);
+    # only for rehearsing the N > 1 path on a 1-GPU box, never for reported numbers.
+    rehearse = os.environ.get("DVO_BENCH_REHEARSE") == "1"
+    local = 0 if rehearse else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearse else dev     # where collective payloads live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     import dvo_amd as dvo
     from dvo_amd import synth
@@ -118,16 +126,16 @@ def main():
         push(batch, 1 + a.warmup + k, poses_out[k])
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     gather_ms = 0.0
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # config 5: gather every rank's poses over RCCL/xGMI (tens of KB: latency bound)
         from dvo_amd import shard
-        local = poses_out.permute(1, 0, 2).contiguous()  # [sequence][frame][6]
+        local_poses = poses_out.permute(1, 0, 2).contiguous().to(cdev)  # [sequence][frame][6]
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        allp, lens = shard.gather_poses(local)
+        allp, lens = shard.gather_poses(local_poses)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert allp.shape[0] == B * world and int(lens.min().item()) == a.steps
