@@ -34,8 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="sequences tracked concurrently per GPU")
-    ap.add_argument("--frames", type=int, default=8, help="distinct frames per sequence kept in HBM (ping-pong order)")
+    ap.add_argument("--batch", type=int, default=512, help="sequences tracked concurrently per GPU")
+    ap.add_argument("--frames", type=int, default=6, help="distinct frames per sequence kept in HBM (ping-pong order)")
     ap.add_argument("--workload", default="syn640", choices=["syn640", "syn1080"])
     ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
     ap.add_argument("--sigma", type=float, default=0.1, help="sensor sigma (src/core/transform.cpp:75)")

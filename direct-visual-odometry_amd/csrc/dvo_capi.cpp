@@ -463,6 +463,7 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     ga.partials = trk.partials.as<float>();
     ga.mask = mask ? mk.as<uint8_t>() : nullptr;
     ga.w = w; ga.h = h; ga.nblk = trk.nblk[level]; ga.inv_w = 1.0f / (float)w;
+    ga.q256 = 256 / w; ga.r256 = 256 % w;
     ga.k = gl.k[level];
     ga.prm = trk.level_params(level);
     ga.ignore_active = 1;

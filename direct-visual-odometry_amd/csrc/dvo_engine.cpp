@@ -248,6 +248,7 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     a.mask = mask;
     a.w = g.w[level]; a.h = g.h[level]; a.nblk = nblk[level];
     a.inv_w = 1.0f / (float)g.w[level];
+    a.q256 = 256 / g.w[level]; a.r256 = 256 % g.w[level];
     a.k = g.k[level];
     a.prm = level_params(level);
     a.ignore_active = ignore_active;

@@ -36,6 +36,7 @@ struct GnArgs {
     uint8_t* mask;           // optional [n_seq][h][w], pre-zeroed
     int w, h, nblk;
     float inv_w;
+    int q256, r256;          // 256 / w and 256 % w: a thread's next pixel is 256 further in raster order
     Intr k;
     GnParams prm;
     int ignore_active;       // 1 on the first iteration of a level / probes

@@ -333,6 +333,16 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
         izA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(izp) + ic);
         wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);
     }
+    // (x, y) of this thread's first pixel by one index split; every further pixel is 256 later in raster order
+    int xA[PPT], yA[PPT];
+    split_index(base < npix ? base : npix - 1, w, a.inv_w, xA[0], yA[0]);
+#pragma unroll
+    for (int k = 1; k < PPT; k++) {
+        const int xn = xA[k - 1] + a.r256;
+        const int wrap = xn >= w ? 1 : 0;
+        xA[k] = xn - wrap * w;
+        yA[k] = yA[k - 1] + a.q256 + wrap;
+    }
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
         float d[G], I1[G], iz[G], wg[G], u[G], v[G];
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
 #pragma unroll
         for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
             const int i = base + (g0 + k) * 256;
-            split_index(i < npix ? i : npix - 1, w, a.inv_w, xs[k], ys[k]);
+            xs[k] = xA[g0 + k]; ys[k] = yA[g0 + k];  // (garbage past the end of the image: gated out by i < npix)
             // gn_gate (optimize.cpp:33-48) written with bitwise ops so it stays a predicate, not a branch
             const int crop_ok = (a.prm.crop == 0) | ((xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100));
             gate[k] = (i < npix) & (crop_ok != 0) & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
@@ -370,7 +380,10 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
 #pragma unroll
         for (int k = 0; k < G; k++) {
             const int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2[k], gx[k], gy[k]);
-            st[k] = gate[k] ? (inter[k] ? s : -1) : 0;
+            // a position outside [0,w) x [0,h) (or NaN) is rejected by optimize.cpp:52-56 whatever the samplers say: only
+            // the one-pixel band along the border and INVALID/NaN taps need the generic sampler
+            const bool inside = (u[k] >= 0.0f) & (v[k] >= 0.0f) & (u[k] < (float)w) & (v[k] < (float)h);
+            st[k] = (gate[k] & inside) ? (inter[k] ? s : -1) : 0;
             any_slow |= st[k] < 0;
         }
         if (any_slow) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
@@ -499,7 +512,8 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         }
         float I2 = 0.0f, gx = 0.0f, gy = 0.0f;
         int s = gn_sample_fast(t, u, v, x0, y0, I2, gx, gy);
-        s = gate ? (inter ? s : -1) : 0;
+        const bool inside = (u >= 0.0f) & (v >= 0.0f) & (u < (float)w) & (v < (float)h);  // outside: rejected (optimize.cpp:52-56)
+        s = (gate & inside) ? (inter ? s : -1) : 0;
         if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
             float o3[3];
             s = gn_sample_slow(refp, w, h, d[k], u, v, o3) ? 1 : 0;
