@@ -198,6 +198,18 @@ def main():
                                "gn_share_of_step_time": pr["gn_ms"] / (dt * 1e3),
                                "top_level_probe": {"avg_launch_us": top_ms * 1e3,
                                                    "achieved": GN_BYTES_PER_PIXEL * top_px / (top_ms * 1e-3) / 1e9}}
+            # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over this same command
+            # (tools/pmc_traffic.sh): a process cannot profile itself, so the committed summary for the matching
+            # workload/batch is quoted here, and null is reported when there is none.
+            if a.workload == "syn640" and a.fixed_iters == 0:
+                import glob
+                for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+                    with open(fn) as fh:
+                        tr = json.load(fh)
+                    if tr.get("kernel") == "k_track_gn" and tr.get("sequences_per_gpu") == B:
+                        out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(fn)
+                        break
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----------
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
