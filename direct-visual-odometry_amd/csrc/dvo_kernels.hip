@@ -238,13 +238,16 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // the generic sampler as a real function: rare (border / INVALID taps), keeps the hot loop's code small
-__device__ __noinline__ bool gn_sample_slow(const float* img, int w, int h, float d, float u, float v, float* out3)
+struct SlowSample {  // returned in registers (an out-pointer would put the caller's locals in scratch memory)
+    float I2, gx, gy;
+    int ok;
+};
+__device__ __noinline__ SlowSample gn_sample_slow(const float* img, int w, int h, float d, float u, float v)
 {
     const GlobalImg ref{img, w, h};
-    float I2, gx, gy;
-    const bool ok = gn_sample(ref, d, u, v, I2, gx, gy);
-    out3[0] = I2; out3[1] = gx; out3[2] = gy;
-    return ok;
+    SlowSample s;
+    s.ok = gn_sample(ref, d, u, v, s.I2, s.gx, s.gy) ? 1 : 0;
+    return s;
 }
 
 // The 12 plus-shaped taps around (x0, y0) that warped gray (4 taps) and its central-difference gradient need.
@@ -302,11 +305,15 @@ template <int PPT, int G, bool MASK>
 __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
 {
     __shared__ float red[4][32];
+    __shared__ int slow_q[4][PPT * 64];  // deferred pixels (generic sampler), one queue per wave
+    __shared__ int slow_cnt[4];
     const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
     const int seq = id / a.nblk, blk = id - seq * a.nblk;
-    const SeqState& st = a.state[seq];
-    if (!a.ignore_active && st.active == 0) return;  // converged sequences cost nothing
-    const Pose pose = st.pose;                        // wave-uniform -> scalar loads
+    const SeqState& sst = a.state[seq];
+    if (!a.ignore_active && sst.active == 0) return;  // converged sequences cost nothing
+    const Pose pose = sst.pose;                       // wave-uniform -> scalar loads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int nslow = 0;                                    // wave-uniform
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
@@ -376,7 +383,6 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
         // sampler runs in a single separate region, then Jacobians and sums again in one straight-line block.
         float I2[G], gx[G], gy[G];
         int st[G];
-        bool any_slow = false;
 #pragma unroll
         for (int k = 0; k < G; k++) {
             const int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2[k], gx[k], gy[k]);
@@ -384,16 +390,18 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             // the one-pixel band along the border and INVALID/NaN taps need the generic sampler
             const bool inside = (u[k] >= 0.0f) & (v[k] >= 0.0f) & (u[k] < (float)w) & (v[k] < (float)h);
             st[k] = (gate[k] & inside) ? (inter[k] ? s : -1) : 0;
-            any_slow |= st[k] < 0;
-        }
-        if (any_slow) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                if (st[k] < 0) {
-                    float o3[3];
-                    st[k] = gn_sample_slow(refp, w, h, d[k], u[k], v[k], o3) ? 1 : 0;
-                    I2[k] = o3[0]; gx[k] = o3[1]; gy[k] = o3[2];
+            // Border, INVALID or NaN taps: the generic sampler decides.  A few lanes per wave need it, so running it here
+            // would cost the whole wave ~350 instructions and several dependent round trips per occurrence; instead the
+            // pixel index is queued (per wave, lane order: deterministic) and the workgroup evaluates all of its deferred
+            // pixels densely after the main loop.
+            const bool slow = st[k] < 0;
+            const unsigned long long bal = __ballot(slow);
+            if (bal != 0ull) {  // wave-uniform
+                if (slow) {
+                    const int pos = nslow + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    slow_q[wave][pos] = base + (g0 + k) * 256;
                 }
+                nslow += __popcll(bal);
             }
         }
 #pragma unroll
@@ -408,8 +416,31 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             if (MASK && ok) a.mask[img_off + base + (g0 + k) * 256] = 1;
         }
     }
+    // deferred pixels: the four wave queues, concatenated in wave order, are spread densely over the workgroup's threads
+    if (lane == 0) slow_cnt[wave] = nslow;
+    __syncthreads();
+    {
+        const int c0 = slow_cnt[0], c1 = c0 + slow_cnt[1], c2 = c1 + slow_cnt[2], total = c2 + slow_cnt[3];
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int qw = (e >= c0) + (e >= c1) + (e >= c2);
+            const int qoff = qw == 0 ? 0 : (qw == 1 ? c0 : (qw == 2 ? c1 : c2));
+            const int i = slow_q[qw][e - qoff];  // < npix (only gated pixels are queued)
+            int x, y;
+            split_index(i, w, a.inv_w, x, y);
+            const float d = dep[i], I1 = obj[i], iz = izp[i], wg = wgp[i];
+            float u, v;
+            warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
+            const SlowSample ss = gn_sample_slow(refp, w, h, d, u, v);
+            const bool ok = ss.ok != 0;
+            float J[6], r, rw;
+            gn_jacobian_pre(a.k, x, y, d, iz, wg, ss.gx, ss.gy, I1, ss.I2, J, r, rw);
+#pragma unroll
+            for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
+            acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
+            if (MASK && ok) a.mask[img_off + i] = 1;
+        }
+    }
     // wave reduction (DPP), then 4 waves through LDS in fixed order
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         float o0, o1;
         wave_reduce29_packed(acc.a, o0, o1);
@@ -515,9 +546,8 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         const bool inside = (u >= 0.0f) & (v >= 0.0f) & (u < (float)w) & (v < (float)h);  // outside: rejected (optimize.cpp:52-56)
         s = (gate & inside) ? (inter ? s : -1) : 0;
         if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
-            float o3[3];
-            s = gn_sample_slow(refp, w, h, d[k], u, v, o3) ? 1 : 0;
-            I2 = o3[0]; gx = o3[1]; gy = o3[2];
+            const SlowSample ss = gn_sample_slow(refp, w, h, d[k], u, v);
+            s = ss.ok; I2 = ss.I2; gx = ss.gx; gy = ss.gy;
         }
         const bool ok = s > 0;
         float J[6], r, rw;
