@@ -216,6 +216,8 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
     DVO_TRY(partials.alloc(sizeof(float) * 32 * max_part * (size_t)n_seq));
     DVO_TRY(log.alloc(sizeof(dvo_track_log) * (size_t)n_seq));
     DVO_TRY(counters.alloc(2 * sizeof(unsigned long long)));
+    DVO_TRY(work.alloc(2 * sizeof(int) * (size_t)(n_seq + 4)));
+    DVO_HIP(hipMemset(work.p, 0, work.bytes));
     DVO_TRY(xi_out.alloc(sizeof(float) * 6 * (size_t)n_seq));
     DVO_TRY(T_out.alloc(sizeof(float) * 16 * (size_t)n_seq));
     DVO_HIP(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
@@ -275,6 +277,12 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         for (int it = 0; it < max_it; it++) {          // tracker.cpp:42
             const int first = (it == 0) ? 1 : 0;
             GnArgs ga = gn_args(obj, ref, level, nullptr, first);
+            // iteration `it` evaluates the sequences k_gn_solve(it - 1) left active (all of them when it == 0) and
+            // clears the list k_gn_solve(it) appends to
+            const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
+            const int* list_prev = (first || !lists) ? nullptr : work_list(it - 1);
+            ga.list = list_prev;
+            ga.next_count = lists ? work_list(it) : nullptr;
             if (cfg.profile) {
                 if (ev_used == ev_pool.size()) {
                     hipEvent_t e0, e1;
@@ -299,6 +307,14 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
             sa.max_iterations = cfg.max_iterations; sa.fixed_iterations = cfg.fixed_iterations;
             sa.min_update = cfg.min_update; sa.min_residual = cfg.min_residual;
             sa.ignore_active = first;
+            sa.list_in = list_prev;
+            sa.list_out = lists ? work_list(it) : nullptr;
+            if (lists) {
+                gn_live_tiles(ga.w, ga.h, ppt[level], nblk[level], ga.prm.crop, sa.blk_first, sa.blk_count);
+                // (profile counter) pixels k_track_gn actually reads: tiles outside the crop rows are never launched
+                const long long T = 256ll * ppt[level], px0 = sa.blk_first * T, px1 = (long long)(sa.blk_first + sa.blk_count) * T;
+                sa.level_pixels = (int)((px1 < sa.level_pixels ? px1 : (long long)sa.level_pixels) - px0);
+            }
             launch_gn_solve(sa, n_seq, s);
             if (poll && it + 1 < max_it) {
                 DVO_HIP(hipMemcpyAsync(host_state, state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));

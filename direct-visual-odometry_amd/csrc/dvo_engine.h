@@ -79,6 +79,8 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int n_seq = 0;
     dvo_config cfg;
     DevBuf state, partials, log, counters, xi_out, T_out;
+    DevBuf work;  // two active-sequence lists ([0] = count, [4..] = ids), written by k_gn_solve, read by the next k_track_gn
+    int* work_list(int i) const { return work.as<int>() + (size_t)(i & 1) * (size_t)(n_seq + 4); }
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll

@@ -39,7 +39,14 @@ struct GnArgs {
     int q256, r256;          // 256 / w and 256 % w: a thread's next pixel is 256 further in raster order
     Intr k;
     GnParams prm;
-    int ignore_active;       // 1 on the first iteration of a level / probes
+    int ignore_active;       // 1 on the first iteration of a level / probes (k_track_gn_tile only; k_track_gn uses `list`)
+    // k_track_gn is launched with a fixed, resident-sized grid whose workgroups stride over the tiles of the ACTIVE
+    // sequences only.  list = nullptr: all n_seq sequences; else list[0] = count and list[4..] = sequence ids
+    // (written by the previous k_gn_solve).  next_count, if set, is zeroed for the k_gn_solve that follows.
+    const int* list = nullptr;
+    int* next_count = nullptr;
+    int n_seq = 1;
+    int blk_first = 0, blk_count = 0;  // live tiles of a sequence (crop window); set by launch_track_gn via gn_live_tiles
     // k_track_gn_tile only: 64 x (4*PPT) pixel tiles with the reference patch staged in LDS
     int tiles_x, tiles_y;    // nblk = tiles_x * tiles_y
     int margin;              // patch = tile grown by margin+1 (left/top) and margin+2 (right/bottom) pixels
@@ -66,7 +73,31 @@ struct SolveArgs {
     int max_iterations, fixed_iterations;
     float min_update, min_residual;
     int ignore_active;         // 1 on the first iteration of a level: every sequence restarts (iter = 0)
+    // active-sequence lists ([0] = count, [4..] = ids): workgroup b handles list_in[4 + b] (nullptr: sequence b) and
+    // appends its sequence to list_out while it stays active (order is irrelevant to the results)
+    const int* list_in = nullptr;
+    int* list_out = nullptr;
+    int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
+
+// Tiles (256 * ppt raster-order pixels) of a w x h level that intersect the crop rows [20, 100] (optimize.cpp:33-36);
+// all of them without crop.  k_track_gn only launches these, k_gn_solve only sums these.
+inline void gn_live_tiles(int w, int h, int ppt, int nblk, int crop, int& first, int& count)
+{
+    first = 0; count = nblk;
+    if (!crop) return;
+    const int T = 256 * ppt, npix = w * h;
+    int lo = nblk, hi = -1;
+    for (int b = 0; b < nblk; b++) {
+        const int row0 = (b * T) / w;
+        int last = b * T + T - 1;
+        if (last > npix - 1) last = npix - 1;
+        const int row1 = last / w;
+        if (row1 >= 20 && row0 <= 100) { if (b < lo) lo = b; if (b > hi) hi = b; }
+    }
+    if (hi < lo) { first = 0; count = 0; return; }
+    first = lo; count = hi - lo + 1;
+}
 
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)
     Pose  pose;        // exp(-r_xi), r_xi = concatenate(obj.xi, -born.xi)

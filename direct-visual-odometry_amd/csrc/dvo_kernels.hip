@@ -302,17 +302,36 @@ __global__ void __launch_bounds__(256) k_prep_ref(PrepArgs a)
 }
 
 template <int PPT, int G, bool MASK>
-__global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
+__global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(GnArgs a)  // 7 waves per SIMD = 72 VGPRs
 {
     __shared__ float red[4][32];
     __shared__ int slow_q[4][PPT * 64];  // deferred pixels (generic sampler), one queue per wave
     __shared__ int slow_cnt[4];
-    const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-    const int seq = id / a.nblk, blk = id - seq * a.nblk;
-    const SeqState& sst = a.state[seq];
-    if (!a.ignore_active && sst.active == 0) return;  // converged sequences cost nothing
-    const Pose pose = sst.pose;                       // wave-uniform -> scalar loads
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: lives in an SGPR
+    // Workgroup 0 clears the counter of the list the following k_gn_solve appends to.  The store comes last on every path:
+    // a store ahead of the list / pose loads would make the compiler fetch those through the vector memory path.
+    auto clear_next = [&]() {
+        if (__builtin_amdgcn_readfirstlane((int)blockIdx.x) == 0 && a.next_count) {  // scalar test first (no VGPR kept for it)
+            if (threadIdx.x == 0) *a.next_count = 0;
+        }
+    };
+    // The grid covers the tiles of all sequences, but only those of the ACTIVE ones exist: the workgroups of XCD x
+    // (blockIdx % 8 == x) take the x-th contiguous eighth of the n_tiles live tiles (neighbouring tiles share an L2) and
+    // every other workgroup leaves after this one scalar load -- converged sequences cost (almost) nothing.
+    // Tiles whose rows all lie outside the crop window (optimize.cpp:33-36) are not launched either: only tiles
+    // [blk_first, blk_first + blk_count) of a sequence exist, and k_gn_solve reads the others as zero.
+    const int n_tiles = (a.list ? a.list[0] : a.n_seq) * a.blk_count;
+    const int t8 = (n_tiles + 7) >> 3, xcd = blockIdx.x & 7, tile_in_xcd = (int)(blockIdx.x >> 3);
+    const int tile_id = xcd * t8 + tile_in_xcd;
+    if (tile_in_xcd >= t8 || tile_id >= n_tiles) {
+        clear_next();
+        return;
+    }
+    const int slot = tile_id / a.blk_count, blk = a.blk_first + (tile_id - slot * a.blk_count);
+    const int seq = a.list ? a.list[4 + slot] : slot;
+    const int w = a.w, h = a.h, npix = w * h;
+    const Pose pose = a.state[seq].pose;              // wave-uniform -> scalar loads
     int nslow = 0;                                    // wave-uniform
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
@@ -320,7 +339,6 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
     const float* __restrict__ izp = a.ref_iz + img_off;
     const float* __restrict__ wgp = a.ref_wgt + img_off;
     const float* __restrict__ refp = a.ref_gray + img_off;
-    const int w = a.w, h = a.h, npix = w * h;
     const int base = blk * (256 * PPT) + threadIdx.x;
     const float wlim = (float)(w - 2), hlim = (float)(h - 2);
 
@@ -430,7 +448,10 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
             const float d = dep[i], I1 = obj[i], iz = izp[i], wg = wgp[i];
             float u, v;
             warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
-            const SlowSample ss = gn_sample_slow(refp, w, h, d, u, v);
+            // inlined (single site): a call here would pin the 29 live accumulators to callee-saved registers and
+            // raise the kernel's VGPR allocation
+            SlowSample ss;
+            ss.ok = gn_sample(GlobalImg{refp, w, h}, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
             const bool ok = ss.ok != 0;
             float J[6], r, rw;
             gn_jacobian_pre(a.k, x, y, d, iz, wg, ss.gx, ss.gy, I1, ss.I2, J, r, rw);
@@ -456,6 +477,7 @@ __global__ void __launch_bounds__(256) k_track_gn(GnArgs a)
         if (c < 29) s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
         a.partials[((size_t)seq * a.nblk + blk) * 32 + c] = s;
     }
+    clear_next();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,7 +607,11 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
 {
     __shared__ double part[8][32];
     __shared__ double tot[32];
-    const int seq = blockIdx.x;
+    int seq = blockIdx.x;
+    if (a.list_in) {  // only the sequences the preceding k_track_gn evaluated
+        if ((int)blockIdx.x >= a.list_in[0]) return;
+        seq = a.list_in[4 + blockIdx.x];
+    }
     SeqState& st = a.state[seq];
     // Everything this kernel needs from memory is requested up front (a fresh kernel starts with cold caches: each
     // dependent round trip costs ~2 us): the state of the sequence and the partial rows.  The active test comes after.
@@ -604,15 +630,20 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         if (c < 29) {
             const float* p = a.partials + (size_t)seq * a.nblk * 32 + c;
             // 8 loads are issued before the first add: one memory round trip per 64 workgroup rows instead of one per row
+            // rows outside the live range were not written by k_track_gn (crop window): they count as exact zeros, in the
+            // same summation slots, so the result is bit-identical to summing stored zeros
+            const int live0 = a.blk_count < 0 ? 0 : a.blk_first, live1 = a.blk_count < 0 ? a.nblk : a.blk_first + a.blk_count;
             for (int b0 = grp; b0 < a.nblk; b0 += 64) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int b = b0 + 8 * j;
-                    v[j] = p[(size_t)(b < a.nblk ? b : b0) * 32];
+                    const bool live = (b >= live0) & (b < live1);
+                    const float x = p[(size_t)(live ? b : b0) * 32];  // (always a valid address: no branch around the load)
+                    v[j] = live ? x : 0.0f;
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) s += (b0 + 8 * j < a.nblk) ? (double)v[j] : 0.0;
+                for (int j = 0; j < 8; j++) s += (double)v[j];
             }
         }
         part[grp][c] = s;
@@ -672,6 +703,7 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         active = 0;  // tracker.cpp:68-73 (the wall-clock term is disabled, D1)
     }
     st.active = active;
+    if (active && a.list_out) a.list_out[4 + atomicAdd(&a.list_out[0], 1)] = seq;
     if (a.counters) {  // profile: evaluated pixels / sequence-iterations
         atomicAdd(&a.counters[0], (unsigned long long)a.level_pixels);
         atomicAdd(&a.counters[1], 1ull);
@@ -1061,15 +1093,20 @@ void launch_warp_image(const float* gray, const float* depth, int w, int h, cons
 int gn_blocks_per_seq(int w, int h, int ppt) { return (int)cdiv((unsigned)(w * h), 256u * (unsigned)ppt); }
 
 template <int PPT, int G>
-static void launch_track_gn_t(const GnArgs& a, const dim3& grid, hipStream_t s)
+static void launch_track_gn_t(const GnArgs& a, unsigned tiles, hipStream_t s)
 {
-    if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_track_gn<PPT, G, false>), grid, dim3(256), 0, s, a);
+    const unsigned g = (tiles + 7u) & ~7u;  // a multiple of 8: blockIdx % 8 is the XCD
+    if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true>), dim3(g), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_track_gn<PPT, G, false>), dim3(g), dim3(256), 0, s, a);
 }
 
-void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s)
+void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_t s)
 {
-    const dim3 grid((unsigned)a.nblk * (unsigned)n_seq);
+    GnArgs a = a0;
+    a.n_seq = n_seq;
+    gn_live_tiles(a.w, a.h, ppt, a.nblk, a.prm.crop, a.blk_first, a.blk_count);
+    unsigned grid = (unsigned)a.blk_count * (unsigned)n_seq;
+    if (grid == 0) grid = 8;  // (nothing live: the workgroups only clear the next list counter)
     switch (ppt * 10 + group) {
         case 11: launch_track_gn_t<1, 1>(a, grid, s); break;
         case 21: launch_track_gn_t<2, 1>(a, grid, s); break;
