@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
     ap.add_argument("--sigma", type=float, default=0.1, help="sensor sigma (src/core/transform.cpp:75)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--streams", type=int, default=0, help="sub-batches tracked on concurrent HIP streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive side measurement (0 = skip)")
@@ -100,7 +101,7 @@ def main():
     t_gen = time.time() - t_gen
 
     stream = torch.cuda.current_stream().cuda_stream
-    cfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters,
+    cfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, track_streams=a.streams,
                              crop_enable=1 if a.workload == "syn640" else 0)
     batch = dvo.Batch(B, K, W, H, levels, culls, cfg=cfg)
     poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
@@ -175,7 +176,7 @@ def main():
 
     # ---- roofline of the dominant kernel (k_track_gn): HIP events around every launch of an identical pass ----
     if not a.no_roofline:
-        pcfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, profile=1,
+        pcfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, profile=1, track_streams=a.streams,
                                   crop_enable=1 if a.workload == "syn640" else 0)
         pb = dvo.Batch(B, K, W, H, levels, culls, cfg=pcfg)
         push(pb, 0)

@@ -37,6 +37,7 @@ void dvo_config_default(dvo_config* c)
     c->gn_pixels_per_thread = 0;
     c->gn_use_lds_patch = -1;
     c->gn_gather_group = 0;
+    c->track_streams = 0;
 }
 
 const char* dvo_version(void) { return "dvo-mi355x 0.1 (gfx950)"; }
@@ -288,9 +289,9 @@ int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, u
     hipEvent_t e0, e1;
     DVO_HIP(hipEventCreate(&e0));
     DVO_HIP(hipEventCreate(&e1));
-    B.trk.launch_gn(ga, level, B.stream);  // warm
+    B.trk.launch_gn(ga, level, B.trk.n_seq, B.stream);  // warm
     DVO_HIP(hipEventRecord(e0, B.stream));
-    for (int i = 0; i < n_launches; i++) B.trk.launch_gn(ga, level, B.stream);
+    for (int i = 0; i < n_launches; i++) B.trk.launch_gn(ga, level, B.trk.n_seq, B.stream);
     DVO_HIP(hipEventRecord(e1, B.stream));
     DVO_HIP(hipEventSynchronize(e1));
     float ms = 0;
@@ -468,7 +469,7 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     ga.prm = trk.level_params(level);
     ga.ignore_active = 1;
     ga.tiles_x = trk.tiles_x[level]; ga.tiles_y = trk.tiles_y[level]; ga.margin = trk.tile_margin;
-    trk.launch_gn(ga, level, c.s);
+    trk.launch_gn(ga, level, 1, c.s);
     SolveArgs sa;
     sa.state = trk.state.as<SeqState>(); sa.partials = trk.partials.as<float>();
     sa.log = nullptr; sa.result = res.as<dvo_gn_result>(); sa.counters = nullptr;

@@ -136,6 +136,15 @@ static void prep_reference(FrameSet& fs, hipStream_t s)
     launch_prep_ref(a, s);
 }
 
+static void fuse_prep(PyramidArgs& a, const FrameSet& fs)
+{
+    for (int l = 0; l < fs.g.levels; l++) {
+        a.iz[l] = fs.iz[l]; a.wgt[l] = fs.wgt[l];
+        a.step[l] = fs.step[l];
+    }
+    a.sigma_min = fs.sigma_min; a.sigma_max = fs.sigma_max;
+}
+
 void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s)
 {
     PyramidArgs a;
@@ -147,8 +156,8 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
         a.dst[0][l] = fs.gray[l]; a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
     }
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
+    if (depth_dev && sigma_dev) fuse_prep(a, fs);  // iz / wgt written by the same launch (no k_prep_ref pass)
     launch_pyramid(a, fs.n_seq, s);
-    if (depth_dev && sigma_dev) prep_reference(fs, s);
 }
 
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s)
@@ -163,14 +172,18 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
         a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
     }
     a.inv_tw = 1.0f / (float)fs.g.w[T];
+    if (depth_top && sigma_top) fuse_prep(a, fs);
     launch_pyramid(a, fs.n_seq, s);
-    prep_reference(fs, s);
+    if (!(depth_top && sigma_top)) prep_reference(fs, s);  // one map only: the other comes from the stored pyramid
 }
 
 // ------------------------------------------------------------------------------------------------ tracker
 Tracker::~Tracker()
 {
     if (h_state) (void)hipHostFree(h_state);
+    for (auto st : sub_streams) (void)hipStreamDestroy(st);
+    for (auto e : ev_join) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto& e : ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -216,7 +229,22 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
     DVO_TRY(partials.alloc(sizeof(float) * 32 * max_part * (size_t)n_seq));
     DVO_TRY(log.alloc(sizeof(dvo_track_log) * (size_t)n_seq));
     DVO_TRY(counters.alloc(2 * sizeof(unsigned long long)));
-    DVO_TRY(work.alloc(2 * sizeof(int) * (size_t)(n_seq + 4)));
+    // sub-batches on concurrent streams: only for the sync-free schedule of big batches (the small-batch poll needs one chain)
+    n_sub = cfg.track_streams;
+    if (n_sub <= 0) n_sub = 1;
+    if (n_sub > 8) n_sub = 8;
+    if (n_seq <= 8 || tile_margin > 0) n_sub = 1;
+    while (n_sub > 1 && n_seq / n_sub < 8) n_sub--;
+    for (int k = 1; k < n_sub; k++) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        DVO_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        sub_streams.push_back(st);
+        DVO_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ev_join.push_back(ev);
+    }
+    if (n_sub > 1) DVO_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    DVO_TRY(work.alloc(2 * sizeof(int) * (size_t)n_sub * (size_t)(n_seq + 4)));
     DVO_HIP(hipMemset(work.p, 0, work.bytes));
     DVO_TRY(xi_out.alloc(sizeof(float) * 6 * (size_t)n_seq));
     DVO_TRY(T_out.alloc(sizeof(float) * 16 * (size_t)n_seq));
@@ -258,10 +286,10 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     return a;
 }
 
-void Tracker::launch_gn(const GnArgs& a, int level, hipStream_t s) const
+void Tracker::launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const
 {
-    if (tile_margin > 0) launch_track_gn_tile(a, n_seq, ppt[level], s);
-    else launch_track_gn(a, n_seq, ppt[level], group[level], s);
+    if (tile_margin > 0) launch_track_gn_tile(a, count, ppt[level], s);
+    else launch_track_gn(a, count, ppt[level], group[level], s);
 }
 
 int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
@@ -273,49 +301,65 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     const bool poll = (cfg.fixed_iterations <= 0) && n_seq <= 8;
     if (poll && !h_state) DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(SeqState) * (size_t)n_seq, hipHostMallocDefault));
     SeqState* host_state = h_state;  // pinned: the read-back is one async copy + one stream sync, no staging
+    // fork: the sub-batch streams start once everything queued on `s` so far (pyramids, k_track_begin) is done
+    const int subs = poll ? 1 : n_sub;
+    if (subs > 1) {
+        DVO_HIP(hipEventRecord(ev_fork, s));
+        for (int k = 1; k < subs; k++) DVO_HIP(hipStreamWaitEvent(sub_streams[k - 1], ev_fork, 0));
+    }
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
+        const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
+        const size_t level_px = (size_t)g.w[level] * g.h[level];
         for (int it = 0; it < max_it; it++) {          // tracker.cpp:42
             const int first = (it == 0) ? 1 : 0;
-            GnArgs ga = gn_args(obj, ref, level, nullptr, first);
-            // iteration `it` evaluates the sequences k_gn_solve(it - 1) left active (all of them when it == 0) and
-            // clears the list k_gn_solve(it) appends to
-            const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
-            const int* list_prev = (first || !lists) ? nullptr : work_list(it - 1);
-            ga.list = list_prev;
-            ga.next_count = lists ? work_list(it) : nullptr;
-            if (cfg.profile) {
-                if (ev_used == ev_pool.size()) {
-                    hipEvent_t e0, e1;
-                    DVO_HIP(hipEventCreate(&e0));
-                    DVO_HIP(hipEventCreate(&e1));
-                    ev_pool.emplace_back(e0, e1);
+            const GnArgs ga0 = gn_args(obj, ref, level, nullptr, first);
+            for (int k = 0; k < subs; k++) {  // launches of the sub-batches interleave on their streams
+                const int q0 = subs > 1 ? sub_first(k) : 0, q1 = subs > 1 ? sub_first(k + 1) : n_seq, nq = q1 - q0;
+                hipStream_t sk = k == 0 ? s : sub_streams[k - 1];
+                GnArgs ga = ga0;  // view of sequences [q0, q1)
+                ga.obj_gray += q0 * level_px; ga.ref_gray += q0 * level_px; ga.ref_depth += q0 * level_px;
+                ga.ref_iz += q0 * level_px; ga.ref_wgt += q0 * level_px;
+                ga.state += q0;
+                ga.partials += (size_t)q0 * nblk[level] * 32;
+                // iteration `it` evaluates the sequences k_gn_solve(it - 1) left active (all of them when it == 0) and
+                // clears the list k_gn_solve(it) appends to
+                const int* list_prev = (first || !lists) ? nullptr : work_list(k, it - 1);
+                ga.list = list_prev;
+                ga.next_count = lists ? work_list(k, it) : nullptr;
+                if (cfg.profile) {
+                    if (ev_used == ev_pool.size()) {
+                        hipEvent_t e0, e1;
+                        DVO_HIP(hipEventCreate(&e0));
+                        DVO_HIP(hipEventCreate(&e1));
+                        ev_pool.emplace_back(e0, e1);
+                    }
+                    DVO_HIP(hipEventRecord(ev_pool[ev_used].first, sk));
+                    launch_gn(ga, level, nq, sk);
+                    DVO_HIP(hipEventRecord(ev_pool[ev_used].second, sk));
+                    ev_used++;
+                } else {
+                    launch_gn(ga, level, nq, sk);
                 }
-                DVO_HIP(hipEventRecord(ev_pool[ev_used].first, s));
-                launch_gn(ga, level, s);
-                DVO_HIP(hipEventRecord(ev_pool[ev_used].second, s));
-                ev_used++;
-            } else {
-                launch_gn(ga, level, s);
+                SolveArgs sa;
+                sa.state = state.as<SeqState>() + q0;
+                sa.partials = ga.partials;
+                sa.log = log.as<dvo_track_log>() + q0;
+                sa.result = nullptr;
+                sa.counters = cfg.profile ? counters.as<unsigned long long>() : nullptr;
+                sa.nblk = nblk[level]; sa.level = level; sa.level_pixels = (int)level_px;
+                sa.max_iterations = cfg.max_iterations; sa.fixed_iterations = cfg.fixed_iterations;
+                sa.min_update = cfg.min_update; sa.min_residual = cfg.min_residual;
+                sa.ignore_active = first;
+                sa.list_in = list_prev;
+                sa.list_out = lists ? work_list(k, it) : nullptr;
+                if (lists) {
+                    gn_live_tiles(ga.w, ga.h, ppt[level], nblk[level], ga.prm.crop, sa.blk_first, sa.blk_count);
+                    // (profile counter) pixels k_track_gn actually reads: tiles outside the crop rows are never launched
+                    const long long T = 256ll * ppt[level], px0 = sa.blk_first * T, px1 = (long long)(sa.blk_first + sa.blk_count) * T;
+                    sa.level_pixels = (int)((px1 < sa.level_pixels ? px1 : (long long)sa.level_pixels) - px0);
+                }
+                launch_gn_solve(sa, nq, sk);
             }
-            SolveArgs sa;
-            sa.state = state.as<SeqState>();
-            sa.partials = partials.as<float>();
-            sa.log = log.as<dvo_track_log>();
-            sa.result = nullptr;
-            sa.counters = cfg.profile ? counters.as<unsigned long long>() : nullptr;
-            sa.nblk = nblk[level]; sa.level = level; sa.level_pixels = g.w[level] * g.h[level];
-            sa.max_iterations = cfg.max_iterations; sa.fixed_iterations = cfg.fixed_iterations;
-            sa.min_update = cfg.min_update; sa.min_residual = cfg.min_residual;
-            sa.ignore_active = first;
-            sa.list_in = list_prev;
-            sa.list_out = lists ? work_list(it) : nullptr;
-            if (lists) {
-                gn_live_tiles(ga.w, ga.h, ppt[level], nblk[level], ga.prm.crop, sa.blk_first, sa.blk_count);
-                // (profile counter) pixels k_track_gn actually reads: tiles outside the crop rows are never launched
-                const long long T = 256ll * ppt[level], px0 = sa.blk_first * T, px1 = (long long)(sa.blk_first + sa.blk_count) * T;
-                sa.level_pixels = (int)((px1 < sa.level_pixels ? px1 : (long long)sa.level_pixels) - px0);
-            }
-            launch_gn_solve(sa, n_seq, s);
             if (poll && it + 1 < max_it) {
                 DVO_HIP(hipMemcpyAsync(host_state, state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));
                 DVO_HIP(hipStreamSynchronize(s));
@@ -324,6 +368,11 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 if (!any) break;
             }
         }
+    }
+    // join: `s` continues (pose export, the caller's next frame) only after every sub-batch chain has finished
+    for (int k = 1; k < subs; k++) {
+        DVO_HIP(hipEventRecord(ev_join[k - 1], sub_streams[k - 1]));
+        DVO_HIP(hipStreamWaitEvent(s, ev_join[k - 1], 0));
     }
     launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s);
     DVO_HIP(hipGetLastError());

@@ -79,13 +79,23 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int n_seq = 0;
     dvo_config cfg;
     DevBuf state, partials, log, counters, xi_out, T_out;
-    DevBuf work;  // two active-sequence lists ([0] = count, [4..] = ids), written by k_gn_solve, read by the next k_track_gn
-    int* work_list(int i) const { return work.as<int>() + (size_t)(i & 1) * (size_t)(n_seq + 4); }
+    // Two active-sequence lists per sub-batch ([0] = count, [4..] = ids local to the sub-batch), written by k_gn_solve,
+    // read by the next k_track_gn.
+    DevBuf work;
+    int* work_list(int sub, int i) const { return work.as<int>() + (size_t)(2 * sub + (i & 1)) * (size_t)(n_seq + 4); }
+    // Sub-batches: the sequences are split into n_sub contiguous groups whose launch chains (k_track_gn -> k_gn_solve ->
+    // ...) run on concurrent HIP streams, so one group's latency-bound solve / launch gaps are covered by another
+    // group's work.  Group 0 uses the caller's stream; fork/join events order the groups against it.
+    int n_sub = 1;
+    std::vector<hipStream_t> sub_streams;  // n_sub - 1 library-owned streams
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+    int sub_first(int k) const { return (int)(((long long)n_seq * k) / n_sub); }
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
-    void launch_gn(const GnArgs& a, int level, hipStream_t s) const;
+    void launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const;  // `a` views `count` sequences
     // profiling (cfg.profile)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;

@@ -23,6 +23,11 @@ struct PyramidArgs {
     int src_w, src_h, culls, levels;
     int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS];
     float inv_tw;                      // 1 / top-level width
+    // optional (iz[0] != nullptr, depth and sigma present): also write the k_prep_ref maps of every level
+    float* iz[DVO_MAX_LEVELS];
+    float* wgt[DVO_MAX_LEVELS];
+    float step[DVO_MAX_LEVELS];
+    float sigma_min, sigma_max;
 };
 
 struct GnArgs {

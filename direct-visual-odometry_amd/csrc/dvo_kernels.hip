@@ -144,18 +144,28 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
     int x, y;
     split_index(i, tw, a.inv_tw, x, y);
     const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << a.culls) * a.src_w + (x << a.culls);
+    float raw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int m = 0; m < 3; m++) {
-        if (a.src[m] == nullptr) continue;
-        const float raw = a.src[m][src_off];
-        const float pv = pass_valid(raw);
-        // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
-        a.dst[m][a.levels - 1][(size_t)seq * tw * th + i] = (a.culls > 0) ? pv : raw;
-        for (int t = 1; t < a.levels; t++) {
-            const int msk = (1 << t) - 1;
-            if ((x & msk) | (y & msk)) break;
-            const int l = a.levels - 1 - t, lx = x >> t, ly = y >> t;
-            if (lx < a.w[l] && ly < a.h[l]) a.dst[m][l][(size_t)seq * a.w[l] * a.h[l] + ly * a.w[l] + lx] = pv;
+    for (int m = 0; m < 3; m++)
+        if (a.src[m] != nullptr) raw[m] = a.src[m][src_off];  // the three loads are in flight together
+    // the reference-frame constants of k_prep_ref, written while depth and sigma are in registers (needs both maps)
+    const bool prep = a.iz[0] != nullptr && a.src[1] != nullptr && a.src[2] != nullptr;
+    for (int t = 0; t < a.levels; t++) {
+        const int msk = (1 << t) - 1;
+        if ((x & msk) | (y & msk)) break;  // level t below the top keeps pixels whose coordinates are multiples of 2^t
+        const int l = a.levels - 1 - t, lx = x >> t, ly = y >> t;
+        if (lx >= a.w[l] || ly >= a.h[l]) continue;
+        const size_t o = (size_t)seq * a.w[l] * a.h[l] + (size_t)ly * a.w[l] + lx;
+        float val[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
+            val[m] = (t == 0 && a.culls == 0) ? raw[m] : pass_valid(raw[m]);
+            if (a.src[m] != nullptr) a.dst[m][l][o] = val[m];
+        }
+        if (prep) {
+            a.iz[l][o] = 1.0f / val[1];
+            a.wgt[l][o] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]);
         }
     }
 }

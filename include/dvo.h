@@ -57,6 +57,7 @@ typedef struct dvo_config {
     int      gn_pixels_per_thread;  /* 0 = choose from the problem size                                  */
     int      gn_use_lds_patch;      /* -1 = auto, 0 = global gathers, 1 = LDS-staged reference patch     */
     int      gn_gather_group;       /* 0 = auto; pixels per thread whose gathers are in flight together  */
+    int      track_streams;         /* 0 = auto; sub-batches of a dvo_batch tracked on concurrent HIP streams */
 } dvo_config;
 
 void        dvo_config_default(dvo_config* cfg);
