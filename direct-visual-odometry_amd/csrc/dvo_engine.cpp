@@ -206,6 +206,7 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         int p = cfg.gn_pixels_per_thread;
         const bool auto_p = (p != 1 && p != 2 && p != 4 && p != 8);
         if (auto_p) p = 4;  // auto: biggest tile that still gives >= 4 workgroups per CU
+        fused[l] = false;
         if (tile_margin > 0) {
             gn_tile_geometry(g.w[l], g.h[l], p, tiles_x[l], tiles_y[l]);
             while (auto_p && p > 1 && (size_t)n_seq * tiles_x[l] * tiles_y[l] < 1024) {
@@ -214,7 +215,15 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
             }
             nblk[l] = tiles_x[l] * tiles_y[l];
         } else {
-            while (auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
+            // small levels: every iteration inside one k_track_level launch (tiles of 256 x 4 pixels)
+            // Off by default: measured on MI355X (512 sequences) the one-workgroup-per-sequence form runs the two coarse
+            // levels in ~1.0 ms against ~0.6 ms for the batched launches -- 2 waves per SIMD cannot hide the latency chain
+            // of a tile, while the batched kernels share the whole chip among the sequences that are still active.
+            const int fuse_max = cfg.track_fused_tiles <= 0 ? 0
+                                                            : (cfg.track_fused_tiles > DVO_FUSED_MAX_TILES ? DVO_FUSED_MAX_TILES : cfg.track_fused_tiles);
+            fused[l] = fuse_max > 0 && gn_blocks_per_seq(g.w[l], g.h[l], 4) <= fuse_max;
+            if (fused[l]) p = 4;
+            while (!fused[l] && auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
             nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p);
             tiles_x[l] = tiles_y[l] = 0;
         }
@@ -310,7 +319,8 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
         const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
         const size_t level_px = (size_t)g.w[level] * g.h[level];
-        for (int it = 0; it < max_it; it++) {          // tracker.cpp:42
+        const int host_its = fused[level] ? 1 : max_it;  // a fused level iterates on the device (k_track_level)
+        for (int it = 0; it < host_its; it++) {        // tracker.cpp:42
             const int first = (it == 0) ? 1 : 0;
             const GnArgs ga0 = gn_args(obj, ref, level, nullptr, first);
             for (int k = 0; k < subs; k++) {  // launches of the sub-batches interleave on their streams
@@ -321,6 +331,20 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 ga.ref_iz += q0 * level_px; ga.ref_wgt += q0 * level_px;
                 ga.state += q0;
                 ga.partials += (size_t)q0 * nblk[level] * 32;
+                if (fused[level]) {
+                    SolveArgs fa;
+                    fa.state = state.as<SeqState>() + q0;
+                    fa.partials = nullptr;
+                    fa.log = log.as<dvo_track_log>() + q0;
+                    fa.result = nullptr;
+                    fa.counters = nullptr;  // (the profile counters describe k_track_gn launches only)
+                    fa.nblk = nblk[level]; fa.level = level; fa.level_pixels = (int)level_px;
+                    fa.max_iterations = cfg.max_iterations; fa.fixed_iterations = cfg.fixed_iterations;
+                    fa.min_update = cfg.min_update; fa.min_residual = cfg.min_residual;
+                    fa.ignore_active = 1;
+                    launch_track_level(ga, fa, nq, sk);
+                    continue;
+                }
                 // iteration `it` evaluates the sequences k_gn_solve(it - 1) left active (all of them when it == 0) and
                 // clears the list k_gn_solve(it) appends to
                 const int* list_prev = (first || !lists) ? nullptr : work_list(k, it - 1);
@@ -360,7 +384,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 }
                 launch_gn_solve(sa, nq, sk);
             }
-            if (poll && it + 1 < max_it) {
+            if (poll && !fused[level] && it + 1 < max_it) {
                 DVO_HIP(hipMemcpyAsync(host_state, state.p, sizeof(SeqState) * (size_t)n_seq, hipMemcpyDeviceToHost, s));
                 DVO_HIP(hipStreamSynchronize(s));
                 bool any = false;

@@ -93,6 +93,7 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int sub_first(int k) const { return (int)(((long long)n_seq * k) / n_sub); }
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
+    bool fused[DVO_MAX_LEVELS];  // level runs as ONE k_track_level launch (all iterations on the device)
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
     void launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const;  // `a` views `count` sequences

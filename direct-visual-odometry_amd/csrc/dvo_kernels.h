@@ -139,6 +139,10 @@ inline void gn_tile_geometry(int w, int h, int ppt, int& tiles_x, int& tiles_y)
     tiles_y = (h + 4 * ppt - 1) / (4 * ppt);
 }
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s);
+// k_track_level: every iteration of one level in one launch (one workgroup per sequence); the level must have been
+// tiled with 4 pixels per thread (ga.nblk = gn_blocks_per_seq(w, h, 4)) and have at most DVO_FUSED_MAX_TILES tiles
+#define DVO_FUSED_MAX_TILES 8
+void launch_track_level(const GnArgs& ga, const SolveArgs& sa, int n_seq, hipStream_t s);
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s);
 void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_t s);
 void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s);

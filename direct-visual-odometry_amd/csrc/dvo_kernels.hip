@@ -282,8 +282,9 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c)
     return m;
 }
 
-__device__ __forceinline__ int gn_sample_fast(const Taps& t, float u, float v, int x0, int y0, float& I2, float& gx, float& gy)
-{  // branch free: everything is computed, the status is selected at the end
+__device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, int x0, int y0, float& I2, float& gx, float& gy,
+                                               bool& decidable, bool& valid)
+{  // branch free: everything is computed; decidable = no INVALID / NaN tap (else: generic path), valid = pixel contributes
     const float mn = min3_raw(min3_raw(min3_raw(t.ra.x, t.ra.y, t.rd.x), min3_raw(t.rb.x, t.rb.y, t.rb.z), min3_raw(t.rc.x, t.rc.y, t.rc.z)),
                               min3_raw(t.rd.y, t.rb.w, t.rc.w), t.rd.y);
     const float hx = u - (float)x0, vy = v - (float)y0;
@@ -291,9 +292,8 @@ __device__ __forceinline__ int gn_sample_fast(const Taps& t, float u, float v, i
     gx = blend4(t.rb.z - t.rb.x, t.rb.w - t.rb.y, t.rc.z - t.rc.x, t.rc.w - t.rc.y, hx, vy);
     gy = blend4(t.rc.y - t.ra.x, t.rc.z - t.ra.y, t.rd.x - t.rb.y, t.rd.y - t.rb.z, hx, vy);
     const float probe = (I2 + gx) + gy;  // a NaN tap (fminf skips NaN) poisons at least one of the three
-    const bool decidable = (mn > kInvalid) && (probe == probe);
-    const bool valid = !(is_invalid(I2) || is_invalid(gx) || is_invalid(gy));
-    return decidable ? (valid ? 1 : 0) : -1;
+    decidable = (mn > kInvalid) & (probe == probe);
+    valid = !(is_invalid(I2) | is_invalid(gx) | is_invalid(gy));
 }
 
 // k_prep_ref: per-pixel constants of a reference frame (all levels, one launch): iz = 1/depth and
@@ -311,14 +311,24 @@ __global__ void __launch_bounds__(256) k_prep_ref(PrepArgs a)
     a.wgt[i] = gn_weight(step, a.sigma_min, a.sigma_max, a.sigma[i]);
 }
 
+// LDS of one gn_tile() evaluation (the caller owns it: k_track_gn once, k_track_level once per tile and iteration)
+template <int PPT>
+struct GnTileLds {
+    float red[4][32];
+    int slow_q[4][PPT * 64];  // deferred pixels (generic sampler), one queue per wave
+    int slow_cnt[4];
+};
+
+// gn_tile: one 256 x PPT pixel tile (`blk`) of sequence `seq` at pose `pose` -> its 32-float partial row `out_row`
+// (global or LDS).  Called by all 256 threads of a workgroup; contains two barriers.
+template <int PPT, int G, bool MASK>
+__device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
+                                        float* out_row);
+
 template <int PPT, int G, bool MASK>
 __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(GnArgs a)  // 7 waves per SIMD = 72 VGPRs
 {
-    __shared__ float red[4][32];
-    __shared__ int slow_q[4][PPT * 64];  // deferred pixels (generic sampler), one queue per wave
-    __shared__ int slow_cnt[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: lives in an SGPR
+    __shared__ GnTileLds<PPT> lds;
     // Workgroup 0 clears the counter of the list the following k_gn_solve appends to.  The store comes last on every path:
     // a store ahead of the list / pose loads would make the compiler fetch those through the vector memory path.
     auto clear_next = [&]() {
@@ -340,8 +350,21 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
     }
     const int slot = tile_id / a.blk_count, blk = a.blk_first + (tile_id - slot * a.blk_count);
     const int seq = a.list ? a.list[4 + slot] : slot;
-    const int w = a.w, h = a.h, npix = w * h;
     const Pose pose = a.state[seq].pose;              // wave-uniform -> scalar loads
+    gn_tile<PPT, G, MASK>(a, pose, seq, blk, lds, a.partials + ((size_t)seq * a.nblk + blk) * 32);
+    clear_next();
+}
+
+template <int PPT, int G, bool MASK>
+__device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
+                                        float* out_row)
+{
+    float (&red)[4][32] = lds.red;
+    int (&slow_q)[4][PPT * 64] = lds.slow_q;
+    int (&slow_cnt)[4] = lds.slow_cnt;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: lives in an SGPR
+    const int w = a.w, h = a.h, npix = w * h;
     int nslow = 0;                                    // wave-uniform
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
@@ -410,19 +433,21 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
         // The G pixels are sampled in ONE straight-line block (independent chains interleave: ILP), the rare generic
         // sampler runs in a single separate region, then Jacobians and sums again in one straight-line block.
         float I2[G], gx[G], gy[G];
-        int st[G];
+        bool okf[G];
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            const int s = gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2[k], gx[k], gy[k]);
-            // a position outside [0,w) x [0,h) (or NaN) is rejected by optimize.cpp:52-56 whatever the samplers say: only
-            // the one-pixel band along the border and INVALID/NaN taps need the generic sampler
+            bool decidable, valid;
+            gn_sample_fast(t[k], u[k], v[k], x0[k], y0[k], I2[k], gx[k], gy[k], decidable, valid);
+            const bool fast = inter[k] & decidable;  // (inter implies gate)
+            okf[k] = fast & valid;
+            // Everything else that passed the gate -- the band along the border, positions outside the image (rejected by
+            // optimize.cpp:52-56), INVALID or NaN taps -- is left to the generic sampler.  A few lanes per wave need it, so
+            // running it here would cost the whole wave ~350 instructions and several dependent round trips per occurrence;
+            // instead the pixel index is queued (per wave, lane order: deterministic) and the workgroup evaluates all of
+            // its deferred pixels densely after the main loop.
+            // (a position outside [0,w) x [0,h), or NaN, is rejected by optimize.cpp:52-56 whatever the samplers say)
             const bool inside = (u[k] >= 0.0f) & (v[k] >= 0.0f) & (u[k] < (float)w) & (v[k] < (float)h);
-            st[k] = (gate[k] & inside) ? (inter[k] ? s : -1) : 0;
-            // Border, INVALID or NaN taps: the generic sampler decides.  A few lanes per wave need it, so running it here
-            // would cost the whole wave ~350 instructions and several dependent round trips per occurrence; instead the
-            // pixel index is queued (per wave, lane order: deterministic) and the workgroup evaluates all of its deferred
-            // pixels densely after the main loop.
-            const bool slow = st[k] < 0;
+            const bool slow = gate[k] & inside & !fast;
             const unsigned long long bal = __ballot(slow);
             if (bal != 0ull) {  // wave-uniform
                 if (slow) {
@@ -435,7 +460,7 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
 #pragma unroll
         for (int k = 0; k < G; k++) {
             // predicated accumulation: rejected pixels add exact zeros, so no control flow merges the 29 accumulators
-            const bool ok = st[k] > 0;
+            const bool ok = okf[k];
             float J[6], r, rw;
             gn_jacobian_pre(a.k, xs[k], ys[k], d[k], iz[k], wg[k], gx[k], gy[k], I1[k], I2[k], J, r, rw);
 #pragma unroll
@@ -485,9 +510,8 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
         const int c = threadIdx.x;
         float s = 0.0f;
         if (c < 29) s = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-        a.partials[((size_t)seq * a.nblk + blk) * 32 + c] = s;
+        out_row[c] = s;
     }
-    clear_next();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,7 +598,9 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
             t.rd = *reinterpret_cast<const f2u*>(p + 2 * w);
         }
         float I2 = 0.0f, gx = 0.0f, gy = 0.0f;
-        int s = gn_sample_fast(t, u, v, x0, y0, I2, gx, gy);
+        bool decidable, valid;
+        gn_sample_fast(t, u, v, x0, y0, I2, gx, gy, decidable, valid);
+        int s = decidable ? (valid ? 1 : 0) : -1;
         const bool inside = (u >= 0.0f) & (v >= 0.0f) & (u < (float)w) & (v < (float)h);  // outside: rejected (optimize.cpp:52-56)
         s = (gate & inside) ? (inter ? s : -1) : 0;
         if (s < 0) {  // border, INVALID or NaN taps: the generic sampler decides (rare; a real function call)
@@ -613,6 +639,9 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
 //   partial sums -> double, fixed order;  xi_update = H^+ g (LDL^T / eigen pseudo-inverse, double);
 //   xi <- log(exp(xi) exp(xi_update)) unless NaN (testXi);  pose <- exp(-xi);  stop tests.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, SeqState& st, const double* tot, const int first,
+                                            const int it_prev, float xi[6], double Tc[12], Pose& np);
+
 __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
 {
     __shared__ double part[8][32];
@@ -664,7 +693,16 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
     __syncthreads();
     if (threadIdx.x != 0) return;
     if (!a.ignore_active && was_active == 0) return;  // converged sequence: nothing to do
+    Pose np;
+    (void)solve_finish(a, seq, st, tot, a.ignore_active, it_prev, xi, Tc, np);
+}
 
+// The serial part of one Tracker::track iteration (tracker.cpp:44-73) for one sequence, run by ONE thread: 6x6 solve,
+// pose update, stop tests, log.  `tot` = the 29 sums in double; xi / Tc = the sequence's twist and exp(+xi) on entry,
+// updated on return (and written to `st`); np = exp(-xi) after the update.  Returns the new active flag.
+__device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, SeqState& st, const double* tot, const int first,
+                                            const int it_prev, float xi[6], double Tc[12], Pose& np)
+{
     const int n_valid = (int)tot[28];
     const double sum_r2 = tot[27];
     float upd[6] = {0, 0, 0, 0, 0, 0};
@@ -673,9 +711,9 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
         solve6(tot, tot + 21, upd);
         residual = (float)sum_r2 / (float)n_valid;  // optimize.cpp:98
     }
-    Pose np;
     // xi <- log(exp(xi) exp(upd)) unless NaN (tracker.cpp:46-51); pose <- exp(-xi) for Stuff::update (optimize.hpp:26-30)
-    if (se3_update_pose(Tc, upd, xi, np)) {
+    const bool updated = se3_update_pose(Tc, upd, xi, np);
+    if (updated) {
 #pragma unroll
         for (int i = 0; i < 6; i++) st.xi[i] = xi[i];
 #pragma unroll
@@ -687,7 +725,7 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
     for (int i = 0; i < 6; i++) nrm += (double)upd[i] * (double)upd[i];
     nrm = sqrt(nrm);
 
-    const int it = a.ignore_active ? 0 : it_prev;
+    const int it = first ? 0 : it_prev;
     if (a.log && it < DVO_MAX_ITERATIONS) {
         dvo_track_log& lg = a.log[seq];
         lg.n_iter[a.level] = it + 1;
@@ -717,6 +755,88 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
     if (a.counters) {  // profile: evaluated pixels / sequence-iterations
         atomicAdd(&a.counters[0], (unsigned long long)a.level_pixels);
         atomicAdd(&a.counters[1], 1ull);
+    }
+    return active | (updated ? 2 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_track_level: ALL iterations of one (coarse) pyramid level for one sequence in one launch -- the loop of
+// tracker.cpp:42-74 on the device.  One workgroup per sequence: every iteration evaluates the level's live tiles with
+// gn_tile() into LDS rows, sums them exactly as k_gn_solve does (same grouping, same order: bit-identical to the
+// k_track_gn + k_gn_solve pair at the same PPT), and thread 0 runs solve_finish(); the workgroup leaves when its
+// sequence stops.  A dependent kernel boundary costs ~8 us on this GPU, whatever the kernel does: for levels of a few
+// tiles the 2 x max_iterations launches of the unfused schedule were all boundary; here there is one.
+// ------------------------------------------------------------------------------------------------
+template <int PPT, int G>
+__global__ void __launch_bounds__(256) k_track_level(GnArgs ga, SolveArgs sa)
+{
+    __shared__ GnTileLds<PPT> lds;
+    __shared__ float rows[DVO_FUSED_MAX_TILES][32];
+    __shared__ double part[8][32];
+    __shared__ double tot[32];
+    __shared__ float pose_s[12];
+    __shared__ int flag_s;
+    const int seq = blockIdx.x;
+    SeqState& st = sa.state[seq];
+    // thread 0 owns the serial state of the sequence across iterations
+    float xi[6];
+    double Tc[12];
+    int it_prev = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) Tc[i] = st.Tc[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) pose_s[i] = st.pose.R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) pose_s[9 + i] = st.pose.t[i];
+    }
+    __syncthreads();
+    const int max_it = sa.fixed_iterations > 0 ? sa.fixed_iterations : sa.max_iterations;
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int live0 = ga.blk_first, live1 = ga.blk_first + ga.blk_count;
+    for (int it = 0; it < max_it; it++) {
+        Pose pose;  // wave-uniform: broadcast from LDS into SGPRs
+#pragma unroll
+        for (int i = 0; i < 9; i++) pose.R[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_s[i])));
+#pragma unroll
+        for (int i = 0; i < 3; i++) pose.t[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_s[9 + i])));
+        for (int blk = live0; blk < live1; blk++) gn_tile<PPT, G, false>(ga, pose, seq, blk, lds, rows[blk]);
+        __syncthreads();
+        {  // second reduction stage, as in k_gn_solve (rows outside the live range are exact zeros)
+            double s = 0.0;
+            if (c < 29) {
+                for (int b0 = grp; b0 < ga.nblk; b0 += 64) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int b = b0 + 8 * j;
+                        const bool live = (b >= live0) & (b < live1);
+                        const float x = rows[live ? b : live0][c];  // (index always inside the array)
+                        s += live ? (double)x : 0.0;
+                    }
+                }
+            }
+            part[grp][c] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32)
+            tot[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Pose np;
+            const int r = solve_finish(sa, seq, st, tot, it == 0 ? 1 : 0, it_prev, xi, Tc, np);
+            it_prev = it + 1;
+            if (r & 2) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) pose_s[i] = np.R[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) pose_s[9 + i] = np.t[i];
+            }
+            flag_s = r & 1;
+        }
+        __syncthreads();
+        if (flag_s == 0) break;
     }
 }
 
@@ -1128,6 +1248,17 @@ void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_
         case 82: launch_track_gn_t<8, 2>(a, grid, s); break;
         default: launch_track_gn_t<8, 4>(a, grid, s); break;
     }
+}
+
+void launch_track_level(const GnArgs& ga0, const SolveArgs& sa0, int n_seq, hipStream_t s)
+{
+    GnArgs ga = ga0;
+    SolveArgs sa = sa0;
+    ga.n_seq = n_seq;
+    ga.list = nullptr; ga.next_count = nullptr; ga.mask = nullptr;
+    gn_live_tiles(ga.w, ga.h, 4, ga.nblk, ga.prm.crop, ga.blk_first, ga.blk_count);  // tiles of 256 x 4 pixels
+    sa.list_in = nullptr; sa.list_out = nullptr; sa.result = nullptr;
+    hipLaunchKernelGGL((k_track_level<4, 2>), dim3((unsigned)n_seq), dim3(256), 0, s, ga, sa);
 }
 
 template <int PPT>

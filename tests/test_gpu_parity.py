@@ -352,3 +352,29 @@ def test_gn_kernel_variants_match_oracle(lds, ppt, group):
     for level in (1, 3):
         rgl = rg if level == 3 else ref.gray(level)
         _gn_compare(obj.gray(level), rgl, ref.depth(level), ref.sigma(level), ref.K(level), xi, level, cfg=cfg)
+
+
+# ---------------------------------------------------------------- schedule variants leave the results untouched
+def test_batch_schedule_variants_are_bit_identical():
+    """Sub-batches on concurrent streams and the one-launch coarse levels (k_track_level) only change WHEN the same
+    arithmetic runs: at the same tile size every pose is bit-identical to the default schedule."""
+    g, d, s, _ = frames(3, sigma=0.5)
+    B = 16
+    order = [(b + np.arange(3)) % 3 for b in range(B)]
+    res = []
+    for kw in ({}, {"track_streams": 2}, {"track_fused_tiles": 8}, {"track_streams": 2, "track_fused_tiles": 8}):
+        cfg = dvo.default_config(gn_pixels_per_thread=4, **kw)
+        bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=cfg)
+        out, logs = [], []
+        for step in range(3):
+            bt.push_host(np.stack([g[order[b][step]] for b in range(B)]), np.stack([d[order[b][step]] for b in range(B)]),
+                         np.stack([s[order[b][step]] for b in range(B)]))
+            if step > 0:
+                out.append(bt.last_poses()[0].copy())
+                logs.append([list(bt.last_track_log(b)["n_iter"][:4]) for b in (0, 5, B - 1)])
+        res.append((np.stack(out), logs))
+        bt.close()
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 1e-4
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        assert res[0][1] == other[1]
