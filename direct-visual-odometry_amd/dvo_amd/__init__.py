@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdvo.so")
+LIB_PATH = os.environ.get("DVO_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdvo.so")  # (override: A/B runs of two builds)
 INVALID = np.float32(-2.0)
 MAX_LEVELS = 8
 MAX_ITERATIONS = 32

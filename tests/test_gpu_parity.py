@@ -378,3 +378,29 @@ def test_batch_schedule_variants_are_bit_identical():
     for other in res[1:]:
         np.testing.assert_array_equal(res[0][0], other[0])
         assert res[0][1] == other[1]
+
+
+def test_batch_many_iterations_every_sequence_matches_single():
+    """sigma = 0.1 (the sensor-depth workload, 10x over-relaxed): sequences run different numbers of iterations, up to
+    the cap, so the active-sequence lists are exercised for real.  At the same tile size every sequence of the batch
+    must reproduce the single-sequence tracker bit for bit (pose AND per-iteration log)."""
+    g, d, s, _ = frames(4, sigma=0.1)
+    pairs = [(i, j) for i in range(4) for j in range(4) if i != j]   # 12 (reference, object) pairs
+    B = len(pairs)
+    cfg = dvo.default_config(gn_pixels_per_thread=4)
+    bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=cfg)
+    bt.push_host(np.stack([g[i] for i, _ in pairs]), np.stack([d[i] for i, _ in pairs]), np.stack([s[i] for i, _ in pairs]))
+    bt.push_host(np.stack([g[j] for _, j in pairs]), np.stack([d[j] for _, j in pairs]), np.stack([s[j] for _, j in pairs]))
+    xb = bt.last_poses()[0].copy()
+    logs = [bt.last_track_log(b) for b in range(B)]
+    bt.close()
+    iters = set()
+    for b, (i, j) in enumerate(pairs):
+        x1, lg = dvo.track(g[j], g[i], d[i], s[i], K640, 4, 1, cfg=cfg)
+        np.testing.assert_array_equal(xb[b], x1)
+        assert list(logs[b]["n_iter"][:4]) == list(lg["n_iter"][:4])
+        for lvl in range(4):
+            n = lg["n_iter"][lvl]
+            np.testing.assert_array_equal(np.asarray(logs[b]["residual"][lvl][:n]), np.asarray(lg["residual"][lvl][:n]))
+            iters.add(n)
+    assert max(iters) >= 5 and len(iters) >= 3   # the case really has long and differing iteration counts
