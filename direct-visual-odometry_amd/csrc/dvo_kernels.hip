@@ -416,14 +416,16 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             const int i = base + (g0 + k) * 256;
             xs[k] = xA[g0 + k]; ys[k] = yA[g0 + k];  // (garbage past the end of the image: gated out by i < npix)
             // gn_gate (optimize.cpp:33-48) written with bitwise ops so it stays a predicate, not a branch
-            const int crop_ok = (a.prm.crop == 0) | ((xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100));
-            gate[k] = (i < npix) & (crop_ok != 0) & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
+            bool crop_ok = true;
+            if (a.prm.crop) crop_ok = (xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100);  // wave-uniform branch
+            gate[k] = (i < npix) & crop_ok & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
             warp(pose, a.k, (float)xs[k], (float)ys[k], d[k], u[k], v[k]);
             inter[k] = gate[k] & (u[k] >= 1.0f) & (v[k] >= 1.0f) & (u[k] < wlim) & (v[k] < hlim);  // false for NaN
             x0[k] = inter[k] ? (int)u[k] : 1;
             y0[k] = inter[k] ? (int)v[k] : 1;
             // unsigned 32-bit element offsets from the wave-uniform base: SGPR-base + VGPR-offset addressing, no 64-bit VALU math
-            const unsigned c = (unsigned)(y0[k] * w + x0[k]) * 4u, uw = (unsigned)w * 4u;  // BYTE offsets (< 2^26)
+            // (24-bit multiply: full rate, v_mul_lo_u32 is quarter rate; y0 < h and w are far below 2^24)
+            const unsigned c = (__umul24((unsigned)y0[k], (unsigned)w) + (unsigned)x0[k]) * 4u, uw = (unsigned)w * 4u;  // BYTE offsets (< 2^26)
             const char* rb8 = reinterpret_cast<const char*>(refp);
             t[k].ra = *reinterpret_cast<const f2u*>(rb8 + (c - uw));
             t[k].rb = *reinterpret_cast<const f4u*>(rb8 + (c - 4u));

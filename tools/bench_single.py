@@ -17,8 +17,9 @@ g, d, s, _ = synth.sequence(16, seed=42, sigma_value=0.1)
 g, d, s = g.numpy(), d.numpy(), s.numpy()
 idx = [i if i < 16 else 30 - i for i in range(31)]
 K = synth.K_640
+FUSED = int(os.environ.get("DVO_FUSED", "0"))  # track_fused_tiles
 for sigma, name in ((0.1, "sensor sigma 0.1 (over-relaxed, many iterations)"), (0.5, "sigma 0.5 (1-2 iterations per level)")):
-    vo = dvo.VisualOdometry(K, 640, 480)
+    vo = dvo.VisualOdometry(K, 640, 480, cfg=dvo.default_config(track_fused_tiles=FUSED))
     ss = np.full_like(s[0], sigma)
     for k in range(3):
         vo.odometrizeUsingDepth(g[idx[k % 30]], d[idx[k % 30]], ss)
@@ -32,7 +33,7 @@ for sigma, name in ((0.1, "sensor sigma 0.1 (over-relaxed, many iterations)"), (
     vo.close()
 # mono tracking + mapping (odometrize)
 import ctypes
-vo = dvo.VisualOdometry(K, 640, 480, cfg=dvo.default_config(rng_seed=1))
+vo = dvo.VisualOdometry(K, 640, 480, cfg=dvo.default_config(rng_seed=1, track_fused_tiles=FUSED))
 d0 = d[0][::4, ::4].copy()
 vo.setInitialDepth(d0, np.full_like(d0, 0.5))
 for k in range(3):
