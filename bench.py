@@ -90,8 +90,11 @@ def main():
     t_gen = time.time()
     gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
     depth = torch.empty_like(gray)
+    gt_poses = []  # world <- camera ground truth of the first sequences (accuracy sample)
     for b in range(B):
         poses = synth.trajectory(F, seed=42 + 1000 * rank + b)
+        if b < 32:
+            gt_poses.append(poses)
         for f in range(F):
             g, d = synth.render(poses[f], K, W, H, device=dev)
             gray[f, b] = g
@@ -157,6 +160,31 @@ def main():
                    "fixed_iterations": a.fixed_iters, "iterations_per_level_seq0": log0["n_iter"],
                    "poses_finite": finite, "gather_ms": gather_ms, "datagen_s": round(t_gen, 2)},
     }
+
+    # ---- accuracy of the timed steps against the synthetic ground truth (BASELINE metric: "ATE RMSE vs reference") ------
+    # exp(xi) maps reference-frame points into the new frame: T_rel = inv(P_new) P_ref for world<-camera poses P.
+    def rel_errors(xis, pairs, poses):
+        et, er = [], []
+        for xi, (fr, fo) in zip(xis, pairs):
+            E = synth.se3_exp_np(np.asarray(xi, np.float64)) @ np.linalg.inv(np.linalg.inv(poses[fo]) @ poses[fr])
+            et.append(float(np.dot(E[:3, 3], E[:3, 3])))
+            er.append(float(np.arccos(np.clip((np.trace(E[:3, :3]) - 1.0) / 2.0, -1.0, 1.0)) ** 2))
+        return et, er
+
+    step_pairs = [(ring_index(a.warmup + k, F), ring_index(1 + a.warmup + k, F)) for k in range(a.steps)]
+    if rank == 0:
+        xs = poses_out[:, :len(gt_poses)].cpu().numpy()  # [steps][sample][6]
+        et, er = [], []
+        for b, poses in enumerate(gt_poses):
+            t_, r_ = rel_errors(xs[:, b], step_pairs, poses)
+            if b == 0:
+                seq0_rmse = float(np.sqrt(np.mean(t_)))
+            et += t_; er += r_
+        out["accuracy"] = {"rel_translation_rmse_m": float(np.sqrt(np.mean(et))), "rel_rotation_rmse_rad": float(np.sqrt(np.mean(er))),
+                           "rel_translation_median_m": float(np.sqrt(np.median(et))), "rel_translation_p90_m": float(np.sqrt(np.percentile(et, 90))),
+                           "sequence0_rel_translation_rmse_m": seq0_rmse,
+                           "sample": "%d sequences x %d timed frame pairs vs the synthetic ground truth "
+                                     "(per-frame motion ~ N(0, 5 mm / 0.3 deg))" % (len(gt_poses), a.steps)}
 
     # ---- PCIe-inclusive rate (reported in config, never `value`): the same steps fed from pinned HOST buffers ----
     if a.pcie_steps > 0:
@@ -235,20 +263,27 @@ def main():
         import orc
         g0 = gray[:, 0].cpu().numpy(); d0 = depth[:, 0].cpu().numpy(); s0 = sigma[:, 0].cpu().numpy()
 
-        def run(variant, budget):
+        def run(variant, budget, xis=None, pairs=None):
             n, t_start = 0, time.perf_counter()
             ref = orc.OFrame(g0[0], d0[0], s0[0], K, levels, culls)
             k = 0
             while time.perf_counter() - t_start < budget:
                 f = ring_index(1 + k, F)
                 obj = orc.OFrame(g0[f], d0[f], s0[f], K, levels, culls)
-                orc.track(obj, ref, crop=(a.workload == "syn640"), variant=variant, fixed_iters=a.fixed_iters)
+                xi, _ = orc.track(obj, ref, crop=(a.workload == "syn640"), variant=variant, fixed_iters=a.fixed_iters)
+                if xis is not None:
+                    xis.append(xi); pairs.append((ring_index(k, F), f))
                 ref = obj
                 n += 1; k += 1
             return n / (time.perf_counter() - t_start), n
 
-        faithful_fps, nf = run(1, a.cpu_seconds)
+        o_xis, o_pairs = [], []
+        faithful_fps, nf = run(1, a.cpu_seconds, o_xis, o_pairs)
         hoisted_fps, nh = run(0, max(3.0, a.cpu_seconds / 3))
+        if "accuracy" in out and gt_poses:  # the same error measure for the CPU restatement on its frame pairs of sequence 0
+            et, er = rel_errors(o_xis, o_pairs, gt_poses[0])
+            out["accuracy"]["cpu_oracle_rel_translation_rmse_m"] = float(np.sqrt(np.mean(et)))
+            out["accuracy"]["cpu_oracle_rel_rotation_rmse_rad"] = float(np.sqrt(np.mean(er)))
         out["cpu_baseline"] = {"value": faithful_fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "%d frame pairs of sequence 0 (same frames, pyramid + track), oracle 'faithful' "
                                          "variant: per-pixel se3 exp, materialised warpImage, Nx6 stack + SVD least squares" % nf,
