@@ -404,3 +404,51 @@ def test_batch_many_iterations_every_sequence_matches_single():
             np.testing.assert_array_equal(np.asarray(logs[b]["residual"][lvl][:n]), np.asarray(lg["residual"][lvl][:n]))
             iters.add(n)
     assert max(iters) >= 5 and len(iters) >= 3   # the case really has long and differing iteration counts
+
+
+# ---------------------------------------------------------------- BASELINE config 4 (1920x1080, 5 levels) and ragged sizes
+def test_syn1080_five_level_parity():
+    """Synthetic 1920x1080 dense alignment, 5-level pyramid, culls 0 (BASELINE.json configs[3]): pyramid bit exact,
+    one Gauss-Newton step per level (masks bit exact) and a fixed-iteration track against the oracle."""
+    from dvo_amd import synth
+    K = synth.K_1080
+    g, d, s, _ = synth.sequence(2, width=1920, height_px=1080, seed=7, sigma_value=0.5)
+    g, d, s = g.numpy(), d.numpy(), s.numpy()
+    ref = orc.OFrame(g[0], d[0], s[0], K, 5, 0)
+    obj = orc.OFrame(g[1], d[1], s[1], K, 5, 0)
+    pg, pd, _ = dvo.pyramid(g[0], d[0], s[0], 5, 0)
+    for l in range(5):
+        np.testing.assert_array_equal(pg[l], ref.gray(l))
+        np.testing.assert_array_equal(pd[l], ref.depth(l))
+    xi = np.array([0.002, -0.001, 0.003, 0.002, -0.001, 0.001], np.float32)
+    cfg = dvo.default_config(crop_enable=0)
+    for l in (0, 2, 4):   # 120x67, 480x270, 1920x1080
+        o, _ = _gn_compare(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, cfg=cfg, crop=False)
+        assert o["n_valid"] > 0.5 * ref.gray(l).size
+    cfg = dvo.default_config(fixed_iterations=2, crop_enable=0)
+    xo, lo = orc.track(obj, ref, crop=False, fixed_iters=2)
+    xg, lg = dvo.track(g[1], g[0], d[0], s[0], K, 5, 0, cfg=cfg)
+    assert lg["n_iter"][:5] == [2] * 5 == lo["n_iter"]
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("w,h,levels,culls", [(322, 243, 3, 0), (161, 121, 2, 0), (646, 486, 4, 1), (37, 29, 1, 0)])
+def test_ragged_sizes_parity(w, h, levels, culls):
+    """Widths that are not multiples of 4 (unaligned rows), tiles that end mid-row, odd pyramid halvings."""
+    from dvo_amd import synth
+    K = np.array(synth.K_640, np.float32).copy()
+    K[0] *= w / 640.0; K[1] *= h / 480.0
+    g, d, s, _ = synth.sequence(2, width=w, height_px=h, K=K, seed=11, sigma_value=0.5)
+    g, d, s = g.numpy(), d.numpy(), s.numpy()
+    ref = orc.OFrame(g[0], d[0], s[0], K, levels, culls)
+    obj = orc.OFrame(g[1], d[1], s[1], K, levels, culls)
+    xi = np.array([0.004, -0.003, 0.002, 0.003, -0.002, 0.004], np.float32)
+    cfg = dvo.default_config(crop_enable=0)
+    for l in range(levels):
+        _gn_compare(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, cfg=cfg, crop=False)
+    got = dvo.Transform.warpImage(xi, ref.gray(levels - 1), ref.depth(levels - 1), ref.K(levels - 1))
+    np.testing.assert_array_equal(got, orc.warp_image(xi, ref.gray(levels - 1), ref.depth(levels - 1), ref.K(levels - 1)))
+    xo, lo = orc.track(obj, ref, crop=False)
+    xg, lg = dvo.track(g[1], g[0], d[0], s[0], K, levels, culls, cfg=cfg)
+    assert lg["n_iter"][:levels] == lo["n_iter"]
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
