@@ -447,9 +447,11 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             // running it here would cost the whole wave ~350 instructions and several dependent round trips per occurrence;
             // instead the pixel index is queued (per wave, lane order: deterministic) and the workgroup evaluates all of
             // its deferred pixels densely after the main loop.
+            const bool cand = gate[k] & !fast;
+            if (__ballot(cand) == 0ull) continue;  // wave-uniform; the common case in the interior of the image
             // (a position outside [0,w) x [0,h), or NaN, is rejected by optimize.cpp:52-56 whatever the samplers say)
             const bool inside = (u[k] >= 0.0f) & (v[k] >= 0.0f) & (u[k] < (float)w) & (v[k] < (float)h);
-            const bool slow = gate[k] & inside & !fast;
+            const bool slow = cand & inside;
             const unsigned long long bal = __ballot(slow);
             if (bal != 0ull) {  // wave-uniform
                 if (slow) {
