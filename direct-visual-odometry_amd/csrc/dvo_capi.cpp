@@ -676,4 +676,21 @@ int dvo_op_se3_concatenate(int dev, const float a[6], const float b[6], float ou
     return (a && b && out) ? se3_op(dev, 2, a, 6, b, out, 6) : DVO_ERR_BAD_ARGUMENT;
 }
 
+int dvo_selftest_reciprocal(int dev, uint64_t* fast_path_inputs, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    if (!mismatches) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(dev));
+    DevBuf out;
+    DVO_TRY(out.alloc(3 * sizeof(unsigned long long)));
+    unsigned long long h[3] = {0ull, 0ull, ~0ull};
+    DVO_HIP(hipMemcpy(out.p, h, sizeof h, hipMemcpyHostToDevice));
+    launch_selftest_reciprocal(out.as<unsigned long long>(), nullptr);
+    DVO_HIP(hipDeviceSynchronize());
+    DVO_HIP(hipMemcpy(h, out.p, sizeof h, hipMemcpyDeviceToHost));
+    if (fast_path_inputs) *fast_path_inputs = h[0];
+    *mismatches = h[1];
+    if (first_bad_bits) *first_bad_bits = (uint32_t)h[2];
+    return DVO_OK;
+}
+
 }  // extern "C"

@@ -1183,6 +1183,29 @@ __global__ void __launch_bounds__(256) k_visualize(int mode, const float* __rest
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------------
+// k_selftest_reciprocal: recip_rn() (dvo_math.h) against the IEEE division for ALL 2^32 float bit patterns.
+// out[0] = patterns that took the rcp + 2 FMA branch, out[1] = mismatching patterns (must be 0), out[2] = smallest bad pattern.
+__global__ void __launch_bounds__(256) k_selftest_reciprocal(unsigned long long* out)
+{
+    unsigned long long fast = 0, bad = 0, first = ~0ull;
+    for (unsigned long long p = blockIdx.x * 256ull + threadIdx.x; p < (1ull << 32); p += (unsigned long long)gridDim.x * 256ull) {
+        const float z = __uint_as_float((unsigned)p);
+        const float az = fabsf(z);
+        const float want = 1.0f / z, got = recip_rn(z);
+        const bool same = (__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want);
+        if (az >= DVO_RECIP_FAST_MIN && az <= DVO_RECIP_FAST_MAX) fast++;
+        if (!same) { bad++; if (p < first) first = p; }
+    }
+    atomicAdd(&out[0], fast);
+    atomicAdd(&out[1], bad);
+    atomicMin(&out[2], first);
+}
+
+void launch_selftest_reciprocal(unsigned long long* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_reciprocal, dim3(8192), dim3(256), 0, s, out);
+}
+
 void launch_visualize(int mode, const float* a, const float* b, int n, uint8_t* rgb, hipStream_t s)
 {
     hipLaunchKernelGGL(k_visualize, dim3((n + 255) / 256), dim3(256), 0, s, mode, a, b, n, rgb);

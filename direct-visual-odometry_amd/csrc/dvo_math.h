@@ -58,9 +58,41 @@ DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float
     Zo = fmaf(p.R[6], X, fmaf(p.R[7], Y, fmaf(p.R[8], Z, p.t[2])));
 }
 
+// Correctly rounded 1/z.  On the device: v_rcp_f32 (1 ulp) + two FMA correction steps (Markstein) for |z| inside
+// [2^-100, 2^100] -- 5 instructions instead of the 11 of the IEEE division sequence -- and the IEEE division
+// outside that range or for non-finite z (never the case for a real depth).  The fast branch equals 1.0f / z for EVERY
+// float in its range: checked exhaustively on the device by dvo_selftest_reciprocal (tests/test_gpu_parity.py), so the
+// result is the same bits as the oracle's x86 division.
+#define DVO_RECIP_FAST_MIN 7.888609052210118e-31f   /* 2^-100 */
+#define DVO_RECIP_FAST_MAX 1.2676506002282294e30f   /* 2^100  */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float recip_fast(float z)  // valid for DVO_RECIP_FAST_MIN <= |z| <= DVO_RECIP_FAST_MAX
+{
+    float r = __builtin_amdgcn_rcpf(z);
+    r = fmaf(fmaf(-z, r, 1.0f), r, r);
+    r = fmaf(fmaf(-z, r, 1.0f), r, r);
+    return r;
+}
+#endif
+DVO_HD float recip_rn(float z)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = recip_fast(z);
+    const float az = fabsf(z);
+    const bool out_of_range = !(az >= DVO_RECIP_FAST_MIN && az <= DVO_RECIP_FAST_MAX);  // (true for NaN)
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull) {  // wave-uniform; never taken for real depths
+        asm volatile("; recip_rn: IEEE division fallback");   // (keeps this a branch: the compiler would otherwise
+        if (out_of_range) r = 1.0f / z;                       //  evaluate both forms and select)
+    }
+    return r;
+#else
+    return 1.0f / z;
+#endif
+}
+
 DVO_HD void project(const Intr& k, float X, float Y, float Z, float& u, float& v)
 {
-    const float iz = 1.0f / Z;  // one correctly rounded reciprocal shared by both coordinates (D8)
+    const float iz = recip_rn(Z);  // one correctly rounded reciprocal shared by both coordinates (D8)
     u = (X * k.fx) * iz + k.cx;
     v = (Y * k.fy) * iz + k.cy;
 }

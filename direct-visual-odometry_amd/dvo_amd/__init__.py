@@ -75,6 +75,7 @@ EXPORTS = [
     "dvo_dataset_close", "dvo_op_ingest", "dvo_vo_odometrize_depth_raw", "dvo_op_undistort",
     "dvo_eval_ate", "dvo_eval_rpe", "dvo_pose_inverse", "dvo_traj_write_tum",
     "dvo_vo_save", "dvo_vo_load", "dvo_vo_set_history_limit", "dvo_op_visualize", "dvo_ppm_write",
+    "dvo_selftest_reciprocal",
 ]
 
 _lib = None
@@ -327,6 +328,13 @@ def visualize(mode, a, b=None, dev=0):
     out = np.zeros((h, w, 3), np.uint8)
     _check(lib().dvo_op_visualize(dev, int(mode), fp(a), fp(bb) if bb is not None else None, w, h, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def selftest_reciprocal(dev=0):
+    """All 2^32 float patterns through the kernels' reciprocal vs the IEEE division: (fast-path inputs, mismatches, first bad bits)."""
+    n = C.c_uint64(); bad = C.c_uint64(); first = C.c_uint32()
+    _check(lib().dvo_selftest_reciprocal(dev, C.byref(n), C.byref(bad), C.byref(first)))
+    return n.value, bad.value, first.value
 
 
 def write_ppm(path, rgb):

@@ -239,6 +239,10 @@ int dvo_vo_set_history_limit(dvo_vo* vo, int max_keyframes);
 int dvo_op_visualize(int dev, int mode, const float* a, const float* b, int w, int h, uint8_t* rgb);
 int dvo_ppm_write(const char* path, const uint8_t* rgb, int w, int h);
 
+/* Device self-test: the kernels' correctly rounded reciprocal (v_rcp_f32 + two FMA corrections inside [2^-100, 2^100], IEEE
+ * division elsewhere) against the IEEE division for all 2^32 float bit patterns.  mismatches must come back 0. */
+int dvo_selftest_reciprocal(int device, uint64_t* fast_path_inputs, uint64_t* mismatches, uint32_t* first_bad_bits);
+
 /* ------------------------------------------------------------------------------------------------
  * Trajectory evaluation / export.  Host side, double precision.
  * ------------------------------------------------------------------------------------------------ */

@@ -452,3 +452,11 @@ def test_ragged_sizes_parity(w, h, levels, culls):
     xg, lg = dvo.track(g[1], g[0], d[0], s[0], K, levels, culls, cfg=cfg)
     assert lg["n_iter"][:levels] == lo["n_iter"]
     np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
+
+
+def test_device_reciprocal_is_ieee_for_every_float():
+    """The per-pixel 1/Z of project() runs as v_rcp_f32 + two FMA corrections inside [2^-100, 2^100] (IEEE division elsewhere).
+    Bit-exact pixel selection rests on it being THE correctly rounded quotient: all 2^32 bit patterns are compared on the device."""
+    n_fast, bad, first = dvo.selftest_reciprocal()
+    assert bad == 0, "first mismatching bit pattern 0x%08x" % first
+    assert n_fast == 2 * (200 * (1 << 23) + 1)   # both signs, exponents 2^-100 .. 2^100 (inclusive end point)
