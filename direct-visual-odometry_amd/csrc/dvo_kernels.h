@@ -85,23 +85,50 @@ struct SolveArgs {
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
 
-// Tiles (256 * ppt raster-order pixels) of a w x h level that intersect the crop rows [20, 100] (optimize.cpp:33-36);
-// all of them without crop.  k_track_gn only launches these, k_gn_solve only sums these.
-inline void gn_live_tiles(int w, int h, int ppt, int nblk, int crop, int& first, int& count)
+// Tile geometry of k_track_gn.  2-D tiles (64 columns x 4*ppt rows) when the level width is a multiple of 64 and ppt = 4,
+// else 256 * ppt consecutive raster pixels.  Every piece of host and device code derives tile counts from these functions.
+inline bool gn_tile2d(int w, int ppt) { return ppt == 4 && w >= 64 && (w % 64) == 0; }
+inline int gn_tile_count(int w, int h, int ppt)
+{
+    if (gn_tile2d(w, ppt)) return (w / 64) * ((h + 4 * ppt - 1) / (4 * ppt));
+    return (w * h + 256 * ppt - 1) / (256 * ppt);
+}
+// Tiles of a w x h level that intersect the crop rows [20, 100] (optimize.cpp:33-36); all of them without crop.
+// k_track_gn only launches these, k_gn_solve only sums these.  `pixels` = image pixels the live tiles cover.
+inline void gn_live_tiles(int w, int h, int ppt, int nblk, int crop, int& first, int& count, long long* pixels = nullptr)
 {
     first = 0; count = nblk;
+    if (pixels) *pixels = (long long)w * h;
     if (!crop) return;
-    const int T = 256 * ppt, npix = w * h;
+    const bool t2d = gn_tile2d(w, ppt);
+    const int tiles_x = t2d ? w / 64 : 1, T = 256 * ppt, R = 4 * ppt, npix = w * h;
     int lo = nblk, hi = -1;
     for (int b = 0; b < nblk; b++) {
-        const int row0 = (b * T) / w;
-        int last = b * T + T - 1;
-        if (last > npix - 1) last = npix - 1;
-        const int row1 = last / w;
+        int row0, row1;
+        if (t2d) {
+            row0 = (b / tiles_x) * R; row1 = row0 + R - 1;
+        } else {
+            row0 = (b * T) / w;
+            int last = b * T + T - 1;
+            if (last > npix - 1) last = npix - 1;
+            row1 = last / w;
+        }
         if (row1 >= 20 && row0 <= 100) { if (b < lo) lo = b; if (b > hi) hi = b; }
     }
-    if (hi < lo) { first = 0; count = 0; return; }
+    if (hi < lo) { first = 0; count = 0; if (pixels) *pixels = 0; return; }
     first = lo; count = hi - lo + 1;
+    if (pixels) {
+        if (t2d) {
+            const int r0 = (lo / tiles_x) * R;
+            int r1 = (hi / tiles_x) * R + R;
+            if (r1 > h) r1 = h;
+            *pixels = (long long)(r1 - r0) * w;
+        } else {
+            long long p1 = (long long)(hi + 1) * T;
+            if (p1 > npix) p1 = npix;
+            *pixels = p1 - (long long)lo * T;
+        }
+    }
 }
 
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)

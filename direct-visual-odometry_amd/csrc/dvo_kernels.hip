@@ -321,11 +321,15 @@ struct GnTileLds {
 
 // gn_tile: one 256 x PPT pixel tile (`blk`) of sequence `seq` at pose `pose` -> its 32-float partial row `out_row`
 // (global or LDS).  Called by all 256 threads of a workgroup; contains two barriers.
-template <int PPT, int G, bool MASK>
+// T2D: the tile is 64 columns x 4*PPT rows (lane = column, wave w owns rows w*PPT .. w*PPT+PPT-1) instead of 256*PPT
+// consecutive raster pixels.  Used when the level width is a multiple of 64: only tiles on the image border then hold
+// deferred (border) pixels, a thread's pixels share their column (one int->float conversion and one (x - cx) for PPT
+// pixels) and there is no row-wrap arithmetic.
+template <int PPT, int G, bool MASK, bool T2D>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row);
 
-template <int PPT, int G, bool MASK>
+template <int PPT, int G, bool MASK, bool T2D = false>
 __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(GnArgs a)  // 7 waves per SIMD = 72 VGPRs
 {
     __shared__ GnTileLds<PPT> lds;
@@ -351,11 +355,11 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
     const int slot = tile_id / a.blk_count, blk = a.blk_first + (tile_id - slot * a.blk_count);
     const int seq = a.list ? a.list[4 + slot] : slot;
     const Pose pose = a.state[seq].pose;              // wave-uniform -> scalar loads
-    gn_tile<PPT, G, MASK>(a, pose, seq, blk, lds, a.partials + ((size_t)seq * a.nblk + blk) * 32);
+    gn_tile<PPT, G, MASK, T2D>(a, pose, seq, blk, lds, a.partials + ((size_t)seq * a.nblk + blk) * 32);
     clear_next();
 }
 
-template <int PPT, int G, bool MASK>
+template <int PPT, int G, bool MASK, bool T2D>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row)
 {
@@ -372,34 +376,53 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
     const float* __restrict__ izp = a.ref_iz + img_off;
     const float* __restrict__ wgp = a.ref_wgt + img_off;
     const float* __restrict__ refp = a.ref_gray + img_off;
-    const int base = blk * (256 * PPT) + threadIdx.x;
     const float wlim = (float)(w - 2), hlim = (float)(h - 2);
 
     Acc29 acc;
     acc.zero();
     // G pixels per thread have their gathers in flight together (memory-level parallelism hides the L2/HBM latency)
     static_assert(PPT % G == 0, "PPT must be a multiple of G");
+    // pixel k of this thread: coordinates (xA, yA), linear index iA (clamped into the image), inA = it exists
+    int xA[PPT], yA[PPT], iA[PPT];
+    bool inA[PPT];
+    if constexpr (T2D) {
+        const int tiles_x = w >> 6;  // (w % 64 == 0)
+        const int ty = blk / tiles_x, tx = blk - ty * tiles_x;
+        const int x = tx * 64 + lane, y0 = ty * (4 * PPT) + wave * PPT;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            xA[k] = x; yA[k] = y0 + k;
+            inA[k] = yA[k] < h;
+            iA[k] = (int)__umul24((unsigned)(inA[k] ? yA[k] : h - 1), (unsigned)w) + x;
+        }
+    } else {
+        const int base = blk * (256 * PPT) + threadIdx.x;
+        // (x, y) of this thread's first pixel by one index split; every further pixel is 256 later in raster order
+        split_index(base < npix ? base : npix - 1, w, a.inv_w, xA[0], yA[0]);
+#pragma unroll
+        for (int k = 1; k < PPT; k++) {
+            const int xn = xA[k - 1] + a.r256;
+            const int wrap = xn >= w ? 1 : 0;
+            xA[k] = xn - wrap * w;
+            yA[k] = yA[k - 1] + a.q256 + wrap;
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int i = base + k * 256;
+            inA[k] = i < npix;  // (coordinates past the end of the image are garbage: gated out)
+            iA[k] = inA[k] ? i : npix - 1;
+        }
+    }
     // every coalesced row load of this thread's PPT pixels is issued up front (independent of the pose): one exposed
     // memory round trip per wave instead of one per group
     float dA[PPT], I1A[PPT], izA[PPT], wgA[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, 1/depth, weight (index clamped: no branch)
-        const int i = base + k * 256;
-        const unsigned ic = (unsigned)(i < npix ? i : npix - 1) * 4u;  // byte offset: SGPR base + 32-bit VGPR offset
+    for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, 1/depth, weight
+        const unsigned ic = (unsigned)iA[k] * 4u;  // byte offset: SGPR base + 32-bit VGPR offset
         dA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dep) + ic);
         I1A[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(obj) + ic);
         izA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(izp) + ic);
         wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);
-    }
-    // (x, y) of this thread's first pixel by one index split; every further pixel is 256 later in raster order
-    int xA[PPT], yA[PPT];
-    split_index(base < npix ? base : npix - 1, w, a.inv_w, xA[0], yA[0]);
-#pragma unroll
-    for (int k = 1; k < PPT; k++) {
-        const int xn = xA[k - 1] + a.r256;
-        const int wrap = xn >= w ? 1 : 0;
-        xA[k] = xn - wrap * w;
-        yA[k] = yA[k - 1] + a.q256 + wrap;
     }
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
@@ -413,12 +436,11 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
         }
 #pragma unroll
         for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
-            const int i = base + (g0 + k) * 256;
-            xs[k] = xA[g0 + k]; ys[k] = yA[g0 + k];  // (garbage past the end of the image: gated out by i < npix)
+            xs[k] = xA[g0 + k]; ys[k] = yA[g0 + k];
             // gn_gate (optimize.cpp:33-48) written with bitwise ops so it stays a predicate, not a branch
             bool crop_ok = true;
             if (a.prm.crop) crop_ok = (xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100);  // wave-uniform branch
-            gate[k] = (i < npix) & crop_ok & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
+            gate[k] = inA[g0 + k] & crop_ok & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
             warp(pose, a.k, (float)xs[k], (float)ys[k], d[k], u[k], v[k]);
             inter[k] = gate[k] & (u[k] >= 1.0f) & (v[k] >= 1.0f) & (u[k] < wlim) & (v[k] < hlim);  // false for NaN
             x0[k] = inter[k] ? (int)u[k] : 1;
@@ -456,7 +478,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             if (bal != 0ull) {  // wave-uniform
                 if (slow) {
                     const int pos = nslow + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    slow_q[wave][pos] = base + (g0 + k) * 256;
+                    slow_q[wave][pos] = iA[g0 + k];
                 }
                 nslow += __popcll(bal);
             }
@@ -470,7 +492,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
 #pragma unroll
             for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
             acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
-            if (MASK && ok) a.mask[img_off + base + (g0 + k) * 256] = 1;
+            if (MASK && ok) a.mask[img_off + iA[g0 + k]] = 1;
         }
     }
     // deferred pixels: the four wave queues, concatenated in wave order, are spread densely over the workgroup's threads
@@ -806,7 +828,7 @@ __global__ void __launch_bounds__(256) k_track_level(GnArgs ga, SolveArgs sa)
         for (int i = 0; i < 9; i++) pose.R[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_s[i])));
 #pragma unroll
         for (int i = 0; i < 3; i++) pose.t[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_s[9 + i])));
-        for (int blk = live0; blk < live1; blk++) gn_tile<PPT, G, false>(ga, pose, seq, blk, lds, rows[blk]);
+        for (int blk = live0; blk < live1; blk++) gn_tile<PPT, G, false, false>(ga, pose, seq, blk, lds, rows[blk]);
         __syncthreads();
         {  // second reduction stage, as in k_gn_solve (rows outside the live range are exact zeros)
             double s = 0.0;
@@ -1247,12 +1269,19 @@ void launch_warp_image(const float* gray, const float* depth, int w, int h, cons
     hipLaunchKernelGGL(k_warp_image, dim3(cdiv(w * h, 256)), dim3(256), 0, s, gray, depth, w, h, k, pose, out);
 }
 
-int gn_blocks_per_seq(int w, int h, int ppt) { return (int)cdiv((unsigned)(w * h), 256u * (unsigned)ppt); }
+int gn_blocks_per_seq(int w, int h, int ppt) { return gn_tile_count(w, h, ppt); }
 
 template <int PPT, int G>
 static void launch_track_gn_t(const GnArgs& a, unsigned tiles, hipStream_t s)
 {
     const unsigned g = (tiles + 7u) & ~7u;  // a multiple of 8: blockIdx % 8 is the XCD
+    if constexpr (PPT == 4) {
+        if (gn_tile2d(a.w, PPT)) {  // 64-column x 16-row tiles
+            if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true, true>), dim3(g), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_track_gn<PPT, G, false, true>), dim3(g), dim3(256), 0, s, a);
+            return;
+        }
+    }
     if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true>), dim3(g), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_track_gn<PPT, G, false>), dim3(g), dim3(256), 0, s, a);
 }
