@@ -145,7 +145,7 @@ static void fuse_prep(PyramidArgs& a, const FrameSet& fs)
     a.sigma_min = fs.sigma_min; a.sigma_max = fs.sigma_max;
 }
 
-void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s)
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma)
 {
     PyramidArgs a;
     memset(&a, 0, sizeof a);
@@ -153,7 +153,8 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
     a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
-        a.dst[0][l] = fs.gray[l]; a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
+        a.dst[0][l] = fs.gray[l]; a.dst[1][l] = fs.depth[l];
+        a.dst[2][l] = (keep_sigma || !(depth_dev && sigma_dev)) ? fs.sigma[l] : nullptr;
     }
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
     if (depth_dev && sigma_dev) fuse_prep(a, fs);  // iz / wgt written by the same launch (no k_prep_ref pass)
@@ -681,7 +682,7 @@ int Batch::push_device(const float* gray, const float* depth, const float* sigma
     if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     const int target = (cur < 0) ? 0 : (cur ^ 1);
-    build_pyramid(fs[target], gray, depth, sigma, stream);  // Frame(gray,depth,sigma,K,levels,culls)
+    build_pyramid(fs[target], gray, depth, sigma, stream, /*keep_sigma=*/false);  // Frame(gray,depth,sigma,K,levels,culls)
     if (cur >= 0) {
         DVO_TRY(trk.track(fs[target], fs[cur], stream));    // system.hpp:88
         have_poses = true;

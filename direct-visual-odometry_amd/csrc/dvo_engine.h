@@ -70,7 +70,8 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
 };
 
 // Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
-void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s);
+// keep_sigma = false: the sigma pyramid is only folded into `wgt`, not stored (frame-to-frame tracking never reads it again)
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma = true);
 // Frame::updateDepthSigma / updateDepth (frame.cpp:39-61): re-decimate from a top-level map (may alias the top level)
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s);
 

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
         for (int m = 0; m < 3; m++) {
             // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
             val[m] = (t == 0 && a.culls == 0) ? raw[m] : pass_valid(raw[m]);
-            if (a.src[m] != nullptr) a.dst[m][l][o] = val[m];
+            if (a.src[m] != nullptr && a.dst[m][l] != nullptr) a.dst[m][l][o] = val[m];  // (a map may be consumed without being kept)
         }
         if (prep) {
             a.iz[l][o] = 1.0f / val[1];
@@ -510,7 +510,9 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             float u, v;
             warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
             // inlined (single site): a call here would pin the 29 live accumulators to callee-saved registers and
-            // raise the kernel's VGPR allocation
+            // raise the kernel's VGPR allocation.  (Tried: the sampler on a register patch of 12 taps loaded up front from
+            // clamped coordinates -- one round trip, no divergent loads.  Slower by 20 % on the probe: the branches of the
+            // memory version skip most of the work for most border pixels.)
             SlowSample ss;
             ss.ok = gn_sample(GlobalImg{refp, w, h}, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
             const bool ok = ss.ok != 0;
