@@ -477,7 +477,10 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     sa.nblk = trk.nblk[level]; sa.level = level; sa.level_pixels = w * h;
     sa.max_iterations = cf.max_iterations; sa.fixed_iterations = cf.fixed_iterations;
     sa.min_update = cf.min_update; sa.min_residual = cf.min_residual; sa.ignore_active = 1;
-    if (trk.tile_margin == 0) gn_live_tiles(w, h, trk.ppt[level], trk.nblk[level], ga.prm.crop, sa.blk_first, sa.blk_count);
+    if (trk.tile_margin == 0) {
+        const GnTiling tl = gn_tiling(w, h, trk.ppt[level], ga.prm.crop);
+        sa.blk_first = tl.live_first; sa.blk_count = tl.live_count;
+    }
     launch_gn_solve(sa, 1, c.s);
     DVO_HIP(hipMemcpyAsync(out, res.p, sizeof *out, hipMemcpyDeviceToHost, c.s));
     if (mask) DVO_HIP(hipMemcpyAsync(mask, mk.p, n, hipMemcpyDeviceToHost, c.s));

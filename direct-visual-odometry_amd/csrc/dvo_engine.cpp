@@ -222,10 +222,12 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
             // of a tile, while the batched kernels share the whole chip among the sequences that are still active.
             const int fuse_max = cfg.track_fused_tiles <= 0 ? 0
                                                             : (cfg.track_fused_tiles > DVO_FUSED_MAX_TILES ? DVO_FUSED_MAX_TILES : cfg.track_fused_tiles);
-            fused[l] = fuse_max > 0 && !gn_tile2d(g.w[l], 4) && gn_blocks_per_seq(g.w[l], g.h[l], 4) <= fuse_max;  // (k_track_level: raster tiles)
+            const int crop_l = level_params(l).crop;
+            const GnTiling t4 = gn_tiling(g.w[l], g.h[l], 4, crop_l);
+            fused[l] = fuse_max > 0 && !t4.t2d && t4.count <= fuse_max;  // (k_track_level: raster tiles)
             if (fused[l]) p = 4;
-            while (!fused[l] && auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p) < 1024) p >>= 1;
-            nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p);
+            while (!fused[l] && auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l) < 1024) p >>= 1;
+            nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l);
             tiles_x[l] = tiles_y[l] = 0;
         }
         ppt[l] = p;
@@ -379,8 +381,9 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 sa.list_out = lists ? work_list(k, it) : nullptr;
                 if (lists) {
                     // (profile counter: the pixels k_track_gn actually reads -- tiles outside the crop rows are never launched)
-                    long long live_px = 0;
-                    gn_live_tiles(ga.w, ga.h, ppt[level], nblk[level], ga.prm.crop, sa.blk_first, sa.blk_count, &live_px);
+                    const GnTiling tl = gn_tiling(ga.w, ga.h, ppt[level], ga.prm.crop);
+                    sa.blk_first = tl.live_first; sa.blk_count = tl.live_count;
+                    const long long live_px = tl.live_pixels;
                     sa.level_pixels = (int)live_px;
                 }
                 launch_gn_solve(sa, nq, sk);

@@ -51,7 +51,8 @@ struct GnArgs {
     const int* list = nullptr;
     int* next_count = nullptr;
     int n_seq = 1;
-    int blk_first = 0, blk_count = 0;  // live tiles of a sequence (crop window); set by launch_track_gn via gn_live_tiles
+    int blk_first = 0, blk_count = 0;  // live tiles of a sequence; set by launch_track_gn from gn_tiling()
+    int t_shift = 6, x_org = 0, y_org = 0;  // 2-D tiles (with tiles_x below): see GnTiling
     // k_track_gn_tile only: 64 x (4*PPT) pixel tiles with the reference patch staged in LDS
     int tiles_x, tiles_y;    // nblk = tiles_x * tiles_y
     int margin;              // patch = tile grown by margin+1 (left/top) and margin+2 (right/bottom) pixels
@@ -85,50 +86,47 @@ struct SolveArgs {
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
 
-// Tile geometry of k_track_gn.  2-D tiles (64 columns x 4*ppt rows) when the level width is a multiple of 64 and ppt = 4,
-// else 256 * ppt consecutive raster pixels.  Every piece of host and device code derives tile counts from these functions.
-inline bool gn_tile2d(int w, int ppt) { return ppt == 4 && w >= 64 && (w % 64) == 0; }
-inline int gn_tile_count(int w, int h, int ppt)
+// Tile geometry of k_track_gn: the single source of tile counts for host and device code.
+//  * raster tiles: 256 * ppt consecutive pixels (any size; tiles outside the crop rows are not live);
+//  * 2-D tiles (ppt = 4): TW = 2^shift columns x (64 / TW) * 16 rows, lane = (column, row-in-wave), wave w owns pixel rows
+//    w*4 .. w*4+3 of the lane's row set.  Used when the width is a multiple of 64 (and the level has no crop window):
+//    64 x 16 tiles over the whole image -- only tiles on the image border hold border pixels.
+struct GnTiling {
+    int t2d = 0, shift = 6, tiles_x = 1, x_org = 0, y_org = 0;
+    int count = 1;                        // tiles (= partial rows) per sequence
+    int live_first = 0, live_count = 0;   // tiles that are launched and summed
+    long long live_pixels = 0;            // image pixels they cover (profile counter)
+};
+inline GnTiling gn_tiling(int w, int h, int ppt, int crop)
 {
-    if (gn_tile2d(w, ppt)) return (w / 64) * ((h + 4 * ppt - 1) / (4 * ppt));
-    return (w * h + 256 * ppt - 1) / (256 * ppt);
-}
-// Tiles of a w x h level that intersect the crop rows [20, 100] (optimize.cpp:33-36); all of them without crop.
-// k_track_gn only launches these, k_gn_solve only sums these.  `pixels` = image pixels the live tiles cover.
-inline void gn_live_tiles(int w, int h, int ppt, int nblk, int crop, int& first, int& count, long long* pixels = nullptr)
-{
-    first = 0; count = nblk;
-    if (pixels) *pixels = (long long)w * h;
-    if (!crop) return;
-    const bool t2d = gn_tile2d(w, ppt);
-    const int tiles_x = t2d ? w / 64 : 1, T = 256 * ppt, R = 4 * ppt, npix = w * h;
-    int lo = nblk, hi = -1;
-    for (int b = 0; b < nblk; b++) {
-        int row0, row1;
-        if (t2d) {
-            row0 = (b / tiles_x) * R; row1 = row0 + R - 1;
-        } else {
-            row0 = (b * T) / w;
+    GnTiling t;
+    const int npix = w * h;
+    // (Tried: 32 x 32 tiles laid over the crop window [20,140] x [20,100] of the crop level, so that no tile touches the image
+    // border and nothing outside the window is evaluated.  No measurable change -- that level's launches are latency chains,
+    // not work -- so the crop level keeps raster tiles; x_org / y_org / shift stay general for it.)
+    if (ppt == 4 && !crop && w >= 64 && (w % 64) == 0) {
+        t.t2d = 1; t.shift = 6; t.tiles_x = w / 64;
+        t.count = t.tiles_x * ((h + 15) / 16);
+        t.live_first = 0; t.live_count = t.count; t.live_pixels = npix;
+        return t;
+    }
+    const int T = 256 * ppt;
+    t.count = (npix + T - 1) / T;
+    t.live_first = 0; t.live_count = t.count; t.live_pixels = npix;
+    if (crop) {
+        int lo = t.count, hi = -1;
+        for (int b = 0; b < t.count; b++) {
+            const int row0 = (b * T) / w;
             int last = b * T + T - 1;
             if (last > npix - 1) last = npix - 1;
-            row1 = last / w;
+            if (last / w >= 20 && row0 <= 100) { if (b < lo) lo = b; if (b > hi) hi = b; }
         }
-        if (row1 >= 20 && row0 <= 100) { if (b < lo) lo = b; if (b > hi) hi = b; }
+        if (hi < lo) { t.live_count = 0; t.live_pixels = 0; return t; }
+        long long p1 = (long long)(hi + 1) * T;
+        if (p1 > npix) p1 = npix;
+        t.live_first = lo; t.live_count = hi - lo + 1; t.live_pixels = p1 - (long long)lo * T;
     }
-    if (hi < lo) { first = 0; count = 0; if (pixels) *pixels = 0; return; }
-    first = lo; count = hi - lo + 1;
-    if (pixels) {
-        if (t2d) {
-            const int r0 = (lo / tiles_x) * R;
-            int r1 = (hi / tiles_x) * R + R;
-            if (r1 > h) r1 = h;
-            *pixels = (long long)(r1 - r0) * w;
-        } else {
-            long long p1 = (long long)(hi + 1) * T;
-            if (p1 > npix) p1 = npix;
-            *pixels = p1 - (long long)lo * T;
-        }
-    }
+    return t;
 }
 
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)
@@ -155,7 +153,7 @@ void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s);
 void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s);
 void launch_gradient(const float* img, int w, int h, int xdir, float* out, hipStream_t s);
 void launch_warp_image(const float* gray, const float* depth, int w, int h, const Intr& k, const Pose& pose, float* out, hipStream_t s);
-int  gn_blocks_per_seq(int w, int h, int ppt);
+int  gn_blocks_per_seq(int w, int h, int ppt, int crop);  // = gn_tiling(...).count
 void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s);
 void launch_prep_ref(const PrepArgs& a, hipStream_t s);
 // LDS-tiled variant: a.tiles_x/tiles_y/margin/nblk must be set (see gn_tile_geometry)

@@ -385,15 +385,17 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
     // pixel k of this thread: coordinates (xA, yA), linear index iA (clamped into the image), inA = it exists
     int xA[PPT], yA[PPT], iA[PPT];
     bool inA[PPT];
-    if constexpr (T2D) {
-        const int tiles_x = w >> 6;  // (w % 64 == 0)
-        const int ty = blk / tiles_x, tx = blk - ty * tiles_x;
-        const int x = tx * 64 + lane, y0 = ty * (4 * PPT) + wave * PPT;
+    if constexpr (T2D) {  // GnTiling (dvo_kernels.h): TW = 2^t_shift columns, 64 / TW rows per wave-load
+        const int sh = a.t_shift, rw = 64 >> sh;
+        const int ty = blk / a.tiles_x, tx = blk - ty * a.tiles_x;
+        const int x = a.x_org + (tx << sh) + (lane & ((1 << sh) - 1));
+        const int y0 = a.y_org + (ty * (4 * PPT) + wave * PPT) * rw + (lane >> sh);
+        const int xc = x < w ? x : w - 1;
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            xA[k] = x; yA[k] = y0 + k;
-            inA[k] = yA[k] < h;
-            iA[k] = (int)__umul24((unsigned)(inA[k] ? yA[k] : h - 1), (unsigned)w) + x;
+            xA[k] = x; yA[k] = y0 + k * rw;
+            inA[k] = (x < w) & (yA[k] < h);
+            iA[k] = (int)__umul24((unsigned)(yA[k] < h ? yA[k] : h - 1), (unsigned)w) + xc;
         }
     } else {
         const int base = blk * (256 * PPT) + threadIdx.x;
@@ -1271,14 +1273,14 @@ void launch_warp_image(const float* gray, const float* depth, int w, int h, cons
     hipLaunchKernelGGL(k_warp_image, dim3(cdiv(w * h, 256)), dim3(256), 0, s, gray, depth, w, h, k, pose, out);
 }
 
-int gn_blocks_per_seq(int w, int h, int ppt) { return gn_tile_count(w, h, ppt); }
+int gn_blocks_per_seq(int w, int h, int ppt, int crop) { return gn_tiling(w, h, ppt, crop).count; }
 
 template <int PPT, int G>
 static void launch_track_gn_t(const GnArgs& a, unsigned tiles, hipStream_t s)
 {
     const unsigned g = (tiles + 7u) & ~7u;  // a multiple of 8: blockIdx % 8 is the XCD
     if constexpr (PPT == 4) {
-        if (gn_tile2d(a.w, PPT)) {  // 64-column x 16-row tiles
+        if (gn_tiling(a.w, a.h, PPT, a.prm.crop).t2d) {  // 2-D tiles
             if (a.mask) hipLaunchKernelGGL((k_track_gn<PPT, G, true, true>), dim3(g), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_track_gn<PPT, G, false, true>), dim3(g), dim3(256), 0, s, a);
             return;
@@ -1292,7 +1294,10 @@ void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_
 {
     GnArgs a = a0;
     a.n_seq = n_seq;
-    gn_live_tiles(a.w, a.h, ppt, a.nblk, a.prm.crop, a.blk_first, a.blk_count);
+    const GnTiling tl = gn_tiling(a.w, a.h, ppt, a.prm.crop);
+    a.blk_first = tl.live_first; a.blk_count = tl.live_count;
+    a.t_shift = tl.shift; a.x_org = tl.x_org; a.y_org = tl.y_org;
+    if (tl.t2d) a.tiles_x = tl.tiles_x;
     unsigned grid = (unsigned)a.blk_count * (unsigned)n_seq;
     if (grid == 0) grid = 8;  // (nothing live: the workgroups only clear the next list counter)
     switch (ppt * 10 + group) {
@@ -1314,7 +1319,8 @@ void launch_track_level(const GnArgs& ga0, const SolveArgs& sa0, int n_seq, hipS
     SolveArgs sa = sa0;
     ga.n_seq = n_seq;
     ga.list = nullptr; ga.next_count = nullptr; ga.mask = nullptr;
-    gn_live_tiles(ga.w, ga.h, 4, ga.nblk, ga.prm.crop, ga.blk_first, ga.blk_count);  // tiles of 256 x 4 pixels
+    const GnTiling tl = gn_tiling(ga.w, ga.h, 4, ga.prm.crop);  // (the caller made sure these are raster tiles: !tl.t2d)
+    ga.blk_first = tl.live_first; ga.blk_count = tl.live_count;
     sa.list_in = nullptr; sa.list_out = nullptr; sa.result = nullptr;
     hipLaunchKernelGGL((k_track_level<4, 2>), dim3((unsigned)n_seq), dim3(256), 0, s, ga, sa);
 }
