@@ -672,9 +672,13 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
 __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, SeqState& st, const double* tot, const int first,
                                             const int it_prev, float xi[6], double Tc[12], Pose& np);
 
-__global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
+// 128 threads (2 waves): at ~250 VGPRs two waves fit a SIMD, so 4 of these workgroups fit a CU and 1024 sequences run in one
+// round (with 256 threads: 512 per round, the second half waited a whole solve).
+#define DVO_SOLVE_THREADS 128
+#define DVO_SOLVE_GROUPS (DVO_SOLVE_THREADS / 32)
+__global__ void __launch_bounds__(DVO_SOLVE_THREADS) k_gn_solve(SolveArgs a)
 {
-    __shared__ double part[8][32];
+    __shared__ double part[DVO_SOLVE_GROUPS][32];
     __shared__ double tot[32];
     int seq = blockIdx.x;
     if (a.list_in) {  // only the sequences the preceding k_track_gn evaluated
@@ -702,11 +706,11 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
             // rows outside the live range were not written by k_track_gn (crop window): they count as exact zeros, in the
             // same summation slots, so the result is bit-identical to summing stored zeros
             const int live0 = a.blk_count < 0 ? 0 : a.blk_first, live1 = a.blk_count < 0 ? a.nblk : a.blk_first + a.blk_count;
-            for (int b0 = grp; b0 < a.nblk; b0 += 64) {
+            for (int b0 = grp; b0 < a.nblk; b0 += 8 * DVO_SOLVE_GROUPS) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const int b = b0 + 8 * j;
+                    const int b = b0 + DVO_SOLVE_GROUPS * j;
                     const bool live = (b >= live0) & (b < live1);
                     const float x = p[(size_t)(live ? b : b0) * 32];  // (always a valid address: no branch around the load)
                     v[j] = live ? x : 0.0f;
@@ -719,7 +723,7 @@ __global__ void __launch_bounds__(256) k_gn_solve(SolveArgs a)
     }
     __syncthreads();
     if (threadIdx.x < 32)
-        tot[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+        tot[c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
     __syncthreads();
     if (threadIdx.x != 0) return;
     if (!a.ignore_active && was_active == 0) return;  // converged sequence: nothing to do
@@ -836,11 +840,11 @@ __global__ void __launch_bounds__(256) k_track_level(GnArgs ga, SolveArgs sa)
         __syncthreads();
         {  // second reduction stage, as in k_gn_solve (rows outside the live range are exact zeros)
             double s = 0.0;
-            if (c < 29) {
-                for (int b0 = grp; b0 < ga.nblk; b0 += 64) {
+            if (c < 29 && grp < DVO_SOLVE_GROUPS) {  // the grouping of k_gn_solve (its 128 threads)
+                for (int b0 = grp; b0 < ga.nblk; b0 += 8 * DVO_SOLVE_GROUPS) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const int b = b0 + 8 * j;
+                        const int b = b0 + DVO_SOLVE_GROUPS * j;
                         const bool live = (b >= live0) & (b < live1);
                         const float x = rows[live ? b : live0][c];  // (index always inside the array)
                         s += live ? (double)x : 0.0;
@@ -851,7 +855,7 @@ __global__ void __launch_bounds__(256) k_track_level(GnArgs ga, SolveArgs sa)
         }
         __syncthreads();
         if (threadIdx.x < 32)
-            tot[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+            tot[c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
         __syncthreads();
         if (threadIdx.x == 0) {
             Pose np;
@@ -1353,7 +1357,7 @@ void launch_prep_ref(const PrepArgs& a, hipStream_t s)
 
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(DVO_SOLVE_THREADS), 0, s, a);
 }
 
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s)
