@@ -38,6 +38,7 @@ void dvo_config_default(dvo_config* c)
     c->gn_use_lds_patch = -1;
     c->gn_gather_group = 0;
     c->track_streams = 0;
+    c->track_adaptive = 0;
     c->track_fused_tiles = 0;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace dvo {
@@ -182,6 +183,7 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
 Tracker::~Tracker()
 {
     if (h_state) (void)hipHostFree(h_state);
+    if (h_progress) (void)hipHostFree(h_progress);
     for (auto st : sub_streams) (void)hipStreamDestroy(st);
     for (auto e : ev_join) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -258,6 +260,14 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
     if (n_sub > 1) DVO_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     DVO_TRY(work.alloc(2 * sizeof(int) * (size_t)n_sub * (size_t)(n_seq + 4)));
     DVO_HIP(hipMemset(work.p, 0, work.bytes));
+    // adaptive schedule (see dvo_engine.h): one launch chain only, global-gather kernel only, reference stop tests only
+    adaptive = cfg.track_adaptive >= 0 && n_sub == 1 && tile_margin == 0 && cfg.fixed_iterations <= 0;
+    if (adaptive) {
+        const size_t words = 2 * (size_t)DVO_MAX_LEVELS * DVO_MAX_ITERATIONS;
+        DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_progress), words * sizeof(int), hipHostMallocMapped | hipHostMallocNonCoherent));
+        memset(h_progress, 0, words * sizeof(int));
+        DVO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_progress), h_progress, 0));
+    }
     DVO_TRY(xi_out.alloc(sizeof(float) * 6 * (size_t)n_seq));
     DVO_TRY(T_out.alloc(sizeof(float) * 16 * (size_t)n_seq));
     DVO_HIP(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
@@ -310,7 +320,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     const int max_it = cfg.fixed_iterations > 0 ? cfg.fixed_iterations : cfg.max_iterations;
     // Small batches: every few iterations ask the device whether anything is still active, so a converged
     // level does not pay for its remaining (empty) launches.  Big batches run the fixed schedule sync-free.
-    const bool poll = (cfg.fixed_iterations <= 0) && n_seq <= 8;
+    const bool poll = (cfg.fixed_iterations <= 0) && n_seq <= 8 && !adaptive;
     if (poll && !h_state) DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_state), sizeof(SeqState) * (size_t)n_seq, hipHostMallocDefault));
     SeqState* host_state = h_state;  // pinned: the read-back is one async copy + one stream sync, no staging
     // fork: the sub-batch streams start once everything queued on `s` so far (pyramids, k_track_begin) is done
@@ -319,12 +329,35 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         DVO_HIP(hipEventRecord(ev_fork, s));
         for (int k = 1; k < subs; k++) DVO_HIP(hipStreamWaitEvent(sub_streams[k - 1], ev_fork, 0));
     }
+    // adaptive: this call's progress words (the other set may still be written by the tail of the previous call)
+    volatile int* prog_h = nullptr;
+    int* prog_d = nullptr;
+    if (adaptive) {
+        progress_set ^= 1;
+        const size_t off = (size_t)progress_set * DVO_MAX_LEVELS * DVO_MAX_ITERATIONS;
+        prog_h = h_progress + off; prog_d = d_progress + off;
+        for (int i = 0; i < DVO_MAX_LEVELS * DVO_MAX_ITERATIONS; i++) prog_h[i] = 0;
+    }
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
         const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
         const size_t level_px = (size_t)g.w[level] * g.h[level];
         const int host_its = fused[level] ? 1 : max_it;  // a fused level iterates on the device (k_track_level)
         for (int it = 0; it < host_its; it++) {        // tracker.cpp:42
             const int first = (it == 0) ? 1 : 0;
+            // Stay `ahead` iterations ahead of the GPU: wait until launch it-ahead of this level has reported, and stop the level
+            // if it had no active sequence -- every later launch of the level would be empty.  Skipping empty launches
+            // changes no result.  (2 for a few sequences, where an iteration is ~16 us of latency and every empty launch
+            // counts; 4 for batches, whose short coarse-level iterations must never find the queue empty.)
+            const int ahead = n_seq <= 8 ? 2 : 4;
+            if (adaptive && !fused[level] && it >= ahead) {
+                volatile int* pw = prog_h + level * DVO_MAX_ITERATIONS + (it - ahead);
+                long spins = 0;
+                while (*pw == 0) {
+                    if (++spins > 2000000000L) { set_error("adaptive schedule: the GPU made no progress"); return DVO_ERR_HIP; }
+                    __builtin_ia32_pause();
+                }
+                if (*pw - 1 == 0) break;
+            }
             const GnArgs ga0 = gn_args(obj, ref, level, nullptr, first);
             for (int k = 0; k < subs; k++) {  // launches of the sub-batches interleave on their streams
                 const int q0 = subs > 1 ? sub_first(k) : 0, q1 = subs > 1 ? sub_first(k + 1) : n_seq, nq = q1 - q0;
@@ -379,6 +412,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 sa.ignore_active = first;
                 sa.list_in = list_prev;
                 sa.list_out = lists ? work_list(k, it) : nullptr;
+                if (adaptive) sa.progress = prog_d + level * DVO_MAX_ITERATIONS + it;
                 if (lists) {
                     // (profile counter: the pixels k_track_gn actually reads -- tiles outside the crop rows are never launched)
                     const GnTiling tl = gn_tiling(ga.w, ga.h, ppt[level], ga.prm.crop);

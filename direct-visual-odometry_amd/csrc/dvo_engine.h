@@ -95,6 +95,13 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
     bool fused[DVO_MAX_LEVELS];  // level runs as ONE k_track_level launch (all iterations on the device)
+    // Adaptive schedule: progress words in mapped host memory, one per (level, iteration), two sets used alternately.
+    // k_gn_solve's workgroup 0 stores (active sequences + 1); the host reads them to stay ~2 iterations ahead of the GPU and
+    // to stop enqueuing a level once a launch reported zero active sequences (its remaining launches would be empty).
+    int* h_progress = nullptr;   // host view
+    int* d_progress = nullptr;   // device view of the same memory
+    int progress_set = 0;
+    bool adaptive = false;
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
     void launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const;  // `a` views `count` sequences

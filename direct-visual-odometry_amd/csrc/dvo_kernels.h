@@ -83,6 +83,7 @@ struct SolveArgs {
     // appends its sequence to list_out while it stays active (order is irrelevant to the results)
     const int* list_in = nullptr;
     int* list_out = nullptr;
+    int* progress = nullptr;   // optional, mapped HOST memory: workgroup 0 stores (sequences this iteration evaluated + 1)
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
 

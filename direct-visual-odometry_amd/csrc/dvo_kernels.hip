@@ -480,7 +480,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             if (bal != 0ull) {  // wave-uniform
                 if (slow) {
                     const int pos = nslow + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    slow_q[wave][pos] = iA[g0 + k];
+                    slow_q[wave][pos] = (int)__umul24((unsigned)ys[k], (unsigned)w) + xs[k];  // (recomputed: iA is dead after the loads)
                 }
                 nslow += __popcll(bal);
             }
@@ -494,7 +494,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
 #pragma unroll
             for (int q = 0; q < 6; q++) J[q] = ok ? J[q] : 0.0f;
             acc.add(J, ok ? r : 0.0f, ok ? rw : 0.0f, ok ? 1.0f : 0.0f);
-            if (MASK && ok) a.mask[img_off + iA[g0 + k]] = 1;
+            if (MASK && ok) a.mask[img_off + (size_t)(ys[k] * w + xs[k])] = 1;
         }
     }
     // deferred pixels: the four wave queues, concatenated in wave order, are spread densely over the workgroup's threads
@@ -680,6 +680,9 @@ __global__ void __launch_bounds__(DVO_SOLVE_THREADS) k_gn_solve(SolveArgs a)
 {
     __shared__ double part[DVO_SOLVE_GROUPS][32];
     __shared__ double tot[32];
+    // progress word in mapped host memory (adaptive schedule, Tracker::track): "iteration reached, n sequences were active".
+    // Kept out of k_track_gn on purpose: that kernel sits exactly at its 72-VGPR budget and one more live value makes it spill.
+    if (a.progress && blockIdx.x == 0 && threadIdx.x == 0) *a.progress = (a.list_in ? a.list_in[0] : (int)gridDim.x) + 1;
     int seq = blockIdx.x;
     if (a.list_in) {  // only the sequences the preceding k_track_gn evaluated
         if ((int)blockIdx.x >= a.list_in[0]) return;

@@ -58,6 +58,7 @@ typedef struct dvo_config {
     int      gn_use_lds_patch;      /* -1 = auto, 0 = global gathers, 1 = LDS-staged reference patch     */
     int      gn_gather_group;       /* 0 = auto; pixels per thread whose gathers are in flight together  */
     int      track_streams;         /* 0 = auto; sub-batches of a dvo_batch tracked on concurrent HIP streams */
+    int      track_adaptive;        /* 0 = auto (on), -1 = off: the host stays two iterations ahead of the GPU and stops a level's launches once no sequence is active */
     int      track_fused_tiles;     /* N > 0: levels of at most N (<= 8) 1024-px tiles run all iterations in ONE launch; 0 = off (default) */
 } dvo_config;
 

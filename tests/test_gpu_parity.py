@@ -460,3 +460,24 @@ def test_device_reciprocal_is_ieee_for_every_float():
     n_fast, bad, first = dvo.selftest_reciprocal()
     assert bad == 0, "first mismatching bit pattern 0x%08x" % first
     assert n_fast == 2 * (200 * (1 << 23) + 1)   # both signs, exponents 2^-100 .. 2^100 (inclusive end point)
+
+
+def test_adaptive_schedule_changes_no_result():
+    """track_adaptive (default): the host stops a level's launches once a launch reported no active sequence.  Skipped launches
+    are empty ones, so poses and logs must equal the fixed schedule's (track_adaptive = -1) bit for bit -- single and batch."""
+    g, d, s, _ = frames(3, sigma=0.1)
+    res = []
+    for adaptive in (0, -1):
+        cfg = dvo.default_config(gn_pixels_per_thread=4, track_adaptive=adaptive)
+        x1, l1 = dvo.track(g[1], g[0], d[0], s[0], K640, 4, 1, cfg=cfg)
+        bt = dvo.Batch(12, K640, 640, 480, 4, 1, cfg=cfg)
+        bt.push_host(np.stack([g[b % 3] for b in range(12)]), np.stack([d[b % 3] for b in range(12)]), np.stack([s[b % 3] for b in range(12)]))
+        bt.push_host(np.stack([g[(b + 1) % 3] for b in range(12)]), np.stack([d[(b + 1) % 3] for b in range(12)]), np.stack([s[(b + 1) % 3] for b in range(12)]))
+        xb = bt.last_poses()[0].copy()
+        nb = [list(bt.last_track_log(b)["n_iter"][:4]) for b in range(12)]
+        bt.close()
+        res.append((x1, list(l1["n_iter"][:4]), xb, nb))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3]
