@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="sub-batches tracked on concurrent HIP streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the single-stream side measurements")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     return ap.parse_args()
 
@@ -266,6 +267,34 @@ def main():
                         out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                         out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(fn)
                         break
+
+    # ---- secondary (N = 1 only, a few seconds): the single-sequence drop-in entry points, host frames in, pose out per call --
+    # BASELINE configs[2] (tracking + inverse-depth filter) and the latency view of configs[1]; never part of `value`.
+    if rank == 0 and world == 1 and a.workload == "syn640" and not a.no_secondary:
+        g0 = gray[:, 0].cpu().numpy(); d0 = depth[:, 0].cpu().numpy(); s0 = sigma[:, 0].cpu().numpy()
+        n_sec = 40
+        vo = dvo.VisualOdometry(K, W, H, cfg=dvo.default_config(device=local))
+        for k in range(3):
+            f = ring_index(k, F); vo.odometrizeUsingDepth(g0[f], d0[f], s0[f])
+        t1 = time.perf_counter(); its = 0
+        for k in range(n_sec):
+            f = ring_index(3 + k, F); vo.odometrizeUsingDepth(g0[f], d0[f], s0[f])
+            its += sum(vo.lastTrackLog()["n_iter"])
+        single_depth = n_sec / (time.perf_counter() - t1)
+        vo.close()
+        vo = dvo.VisualOdometry(K, W, H, cfg=dvo.default_config(device=local, rng_seed=1))
+        di = d0[0][::4, ::4].copy()
+        vo.setInitialDepth(di, np.full_like(di, 0.5))
+        for k in range(3):
+            vo.odometrize(g0[ring_index(k, F)])
+        t1 = time.perf_counter(); keys = 0
+        for k in range(n_sec):
+            _, key = vo.odometrize(g0[ring_index(3 + k, F)]); keys += int(key)
+        single_mono = n_sec / (time.perf_counter() - t1)
+        vo.close()
+        out["secondary"] = {"single_stream_odometrizeUsingDepth_fps": single_depth, "single_stream_odometrize_mono_track_map_fps": single_mono,
+                            "depth_gn_iterations_per_frame": its / n_sec, "mono_keyframes": keys, "frames": n_sec,
+                            "note": "one dvo_vo handle, 640x480 host frames in / pose out per call (PCIe and launch latency included)"}
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----------
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
