@@ -84,6 +84,7 @@ struct SolveArgs {
     const int* list_in = nullptr;
     int* list_out = nullptr;
     int* progress = nullptr;   // optional, mapped HOST memory: workgroup 0 stores (sequences this iteration evaluated + 1)
+    int n_seq = 1;             // sequences of the launch (set by launch_gn_solve)
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
 

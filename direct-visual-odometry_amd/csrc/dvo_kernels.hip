@@ -672,66 +672,73 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
 __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, SeqState& st, const double* tot, const int first,
                                             const int it_prev, float xi[6], double Tc[12], Pose& np);
 
-// 128 threads (2 waves): at ~250 VGPRs two waves fit a SIMD, so 4 of these workgroups fit a CU and 1024 sequences run in one
-// round (with 256 threads: 512 per round, the second half waited a whole solve).
-#define DVO_SOLVE_THREADS 128
-#define DVO_SOLVE_GROUPS (DVO_SOLVE_THREADS / 32)
-__global__ void __launch_bounds__(DVO_SOLVE_THREADS) k_gn_solve(SolveArgs a)
+// DVO_SOLVE_SEQ sequences per 256-thread workgroup.  The serial chain below (6x6 solve, exp / log in double: ~4.4 us,
+// ~250 VGPRs) is the same instruction stream for every sequence, so lanes 0..7 of wave 0 run it for 8 sequences in lockstep
+// at the price of one; with one sequence per workgroup a 4096-sequence batch needed several rounds of workgroups, each
+// waiting out a full chain.  Stage one: team t (32 lanes = the 32 columns of a partial row) sums the rows of sequence t.
+#define DVO_SOLVE_SEQ 8
+#define DVO_SOLVE_GROUPS 4   /* row classes of the fixed summation order: rows b = g (mod 4) in batches of 8, then (s0+s1)+(s2+s3) */
+__global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
 {
-    __shared__ double part[DVO_SOLVE_GROUPS][32];
-    __shared__ double tot[32];
+    __shared__ double tot[DVO_SOLVE_SEQ][32];
+    const int n_in = a.list_in ? a.list_in[0] : a.n_seq;  // sequences this launch handles
     // progress word in mapped host memory (adaptive schedule, Tracker::track): "iteration reached, n sequences were active".
     // Kept out of k_track_gn on purpose: that kernel sits exactly at its 72-VGPR budget and one more live value makes it spill.
-    if (a.progress && blockIdx.x == 0 && threadIdx.x == 0) *a.progress = (a.list_in ? a.list_in[0] : (int)gridDim.x) + 1;
-    int seq = blockIdx.x;
-    if (a.list_in) {  // only the sequences the preceding k_track_gn evaluated
-        if ((int)blockIdx.x >= a.list_in[0]) return;
-        seq = a.list_in[4 + blockIdx.x];
-    }
-    SeqState& st = a.state[seq];
+    if (a.progress && blockIdx.x == 0 && threadIdx.x == 0) *a.progress = n_in + 1;
+    if ((int)blockIdx.x * DVO_SOLVE_SEQ >= n_in) return;
     // Everything this kernel needs from memory is requested up front (a fresh kernel starts with cold caches: each
-    // dependent round trip costs ~2 us): the state of the sequence and the partial rows.  The active test comes after.
-    const int was_active = st.active, it_prev = st.iter;
-    float xi[6];
-    double Tc[12];
+    // dependent round trip costs ~2 us): lanes 0..7 the state of their sequence, every team its partial rows.
+    const int my_slot = (int)blockIdx.x * DVO_SOLVE_SEQ + (int)threadIdx.x;   // (serial stage: threads 0..7)
+    const bool serial = threadIdx.x < DVO_SOLVE_SEQ && my_slot < n_in;
+    int my_seq = 0;
+    if (serial) my_seq = a.list_in ? a.list_in[4 + my_slot] : my_slot;
+    SeqState& st = a.state[my_seq];
+    int was_active = 0, it_prev = 0;
+    float xi[6] = {0, 0, 0, 0, 0, 0};
+    double Tc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (serial) {
+        was_active = st.active; it_prev = st.iter;
 #pragma unroll
-    for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
+        for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
 #pragma unroll
-    for (int i = 0; i < 12; i++) Tc[i] = st.Tc[i];
-    // second reduction stage: 8 groups of 32 lanes stride over the workgroup partials (many loads in flight instead
-    // of one dependent chain), then the 8 group sums are added in a fixed order -> still bit-reproducible
-    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    {
-        double s = 0.0;
-        if (c < 29) {
-            const float* p = a.partials + (size_t)seq * a.nblk * 32 + c;
-            // 8 loads are issued before the first add: one memory round trip per 64 workgroup rows instead of one per row
-            // rows outside the live range were not written by k_track_gn (crop window): they count as exact zeros, in the
-            // same summation slots, so the result is bit-identical to summing stored zeros
-            const int live0 = a.blk_count < 0 ? 0 : a.blk_first, live1 = a.blk_count < 0 ? a.nblk : a.blk_first + a.blk_count;
-            for (int b0 = grp; b0 < a.nblk; b0 += 8 * DVO_SOLVE_GROUPS) {
-                float v[8];
+        for (int i = 0; i < 12; i++) Tc[i] = st.Tc[i];
+    }
+    // stage one: second reduction of the workgroup partials, fixed order (bit-reproducible; k_track_level mirrors it)
+    const int c = threadIdx.x & 31, team = threadIdx.x >> 5;
+    const int t_slot = (int)blockIdx.x * DVO_SOLVE_SEQ + team;
+    if (t_slot < n_in && c < 29) {
+        const int t_seq = a.list_in ? a.list_in[4 + t_slot] : t_slot;
+        const float* p = a.partials + (size_t)t_seq * a.nblk * 32 + c;
+        // rows outside the live range were not written by k_track_gn (crop window): they count as exact zeros, in the
+        // same summation slots, so the result is bit-identical to summing stored zeros
+        const int live0 = a.blk_count < 0 ? 0 : a.blk_first, live1 = a.blk_count < 0 ? a.nblk : a.blk_first + a.blk_count;
+        double sg[DVO_SOLVE_GROUPS] = {0.0, 0.0, 0.0, 0.0};
+        for (int b0 = 0; b0 < a.nblk; b0 += 8 * DVO_SOLVE_GROUPS) {  // 32 loads in flight per lane
+            float v[DVO_SOLVE_GROUPS][8];
+#pragma unroll
+            for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const int b = b0 + DVO_SOLVE_GROUPS * j;
+                    const int b = b0 + g + DVO_SOLVE_GROUPS * j;
                     const bool live = (b >= live0) & (b < live1);
-                    const float x = p[(size_t)(live ? b : b0) * 32];  // (always a valid address: no branch around the load)
-                    v[j] = live ? x : 0.0f;
+                    const float x = p[(size_t)(live ? b : 0) * 32];  // (always a valid address: no branch around the load)
+                    v[g][j] = live ? x : 0.0f;
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) s += (double)v[j];
-            }
+            for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (b0 + g < a.nblk) sg[g] += (double)v[g][j];  // (a class with no row left adds nothing, as before)
         }
-        part[grp][c] = s;
+        tot[team][c] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    } else if (c >= 29) {
+        tot[team][c] = 0.0;
     }
     __syncthreads();
-    if (threadIdx.x < 32)
-        tot[c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (!serial) return;
     if (!a.ignore_active && was_active == 0) return;  // converged sequence: nothing to do
     Pose np;
-    (void)solve_finish(a, seq, st, tot, a.ignore_active, it_prev, xi, Tc, np);
+    (void)solve_finish(a, my_seq, st, tot[threadIdx.x], a.ignore_active, it_prev, xi, Tc, np);
 }
 
 // The serial part of one Tracker::track iteration (tracker.cpp:44-73) for one sequence, run by ONE thread: 6x6 solve,
@@ -1360,7 +1367,9 @@ void launch_prep_ref(const PrepArgs& a, hipStream_t s)
 
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gn_solve, dim3(n_seq), dim3(DVO_SOLVE_THREADS), 0, s, a);
+    SolveArgs b = a;
+    b.n_seq = n_seq;
+    hipLaunchKernelGGL(k_gn_solve, dim3((unsigned)((n_seq + DVO_SOLVE_SEQ - 1) / DVO_SOLVE_SEQ)), dim3(32 * DVO_SOLVE_SEQ), 0, s, b);
 }
 
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s)
