@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd $R && python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err && echo "bench done" &&
 cd /tmp && export TMPDIR=/tmp &&
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --no-cpu-baseline --pcie-steps 0 > /tmp/prof_$TAG.json 2> /tmp/prof_$TAG.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --no-cpu-baseline --pcie-steps 0 --no-secondary > /tmp/prof_$TAG.json 2> /tmp/prof_$TAG.err &&
 cp /tmp/prof_$TAG/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv && cp /tmp/prof_$TAG.json $R/gpurun_out/${TAG}_bench_under_rocprof.json && echo "stats done" &&
 bash $R/tools/pmc_gn.sh 0.5 4 2 64 > /dev/null 2>&1; cp /tmp/pmc_all.txt $R/gpurun_out/${TAG}_k_track_gn_pmc.txt && echo "pmc done" &&
 bash $R/tools/pmc_traffic.sh > /dev/null 2>&1; cp $R/gpurun_out/traffic.json $R/gpurun_out/${TAG}_traffic.json && echo "traffic done"

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=/tmp/pmct_$$
-ARGS="--no-cpu-baseline --pcie-steps 0 --no-roofline $*"
+ARGS="--no-cpu-baseline --pcie-steps 0 --no-roofline --no-secondary $*"
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_track_gn --output-format csv -d $OUT/f -- python3 $R/bench.py $ARGS > $OUT.f.json 2> $OUT.f.err || tail -3 $OUT.f.err
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_track_gn --output-format csv -d $OUT/w -- python3 $R/bench.py $ARGS > $OUT.w.json 2> $OUT.w.err || tail -3 $OUT.w.err
 python3 - "$OUT" "$OUT.f.json" > $R/gpurun_out/traffic.json <<'PY'
