@@ -87,3 +87,38 @@ def test_cpp_facade_header_compiles():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name], capture_output=True, text=True)
     os.unlink(f.name)
     assert r.returncode == 0, r.stderr
+
+
+def test_hot_kernel_fits_its_register_budget():
+    """k_track_gn is built for 7 waves per SIMD (72 VGPRs) and its time is proportional to its instruction count: one
+    spilled register costs tens of percent (measured).  The default variants must compile without scratch memory."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    pkg = os.path.join(ROOT, "direct-visual-odometry_amd")
+    flags = None
+    for line in open(os.path.join(pkg, "Makefile")):
+        if line.startswith("FLAGS"):
+            flags = line.split("=", 1)[1].strip().rstrip("\\").split()
+    cont = open(os.path.join(pkg, "Makefile")).read().split("FLAGS   =", 1)[1].split("\n")
+    flags = (cont[0].rstrip("\\") + " " + cont[1]).split()
+    flags = [f.replace("$(ARCH)", "gfx950") for f in flags if f != "-fPIC"]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(pkg, "csrc", "dvo_kernels.hip")],
+                       check=True, capture_output=True, timeout=900)
+        txt = open(out).read()
+    checked = 0
+    for variant in ("ILi4ELi2ELb0ELb0E", "ILi4ELi2ELb0ELb1E"):   # <PPT 4, G 2, no mask, raster | 2-D tiles>
+        m = re.search(r"\.amdhsa_kernel _ZN3dvo10k_track_gn%s.*?\.end_amdhsa_kernel" % variant, txt, re.S)
+        assert m, "kernel variant not found: " + variant
+        body = m.group(0)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert scratch == 0, "%s spills %d bytes of scratch per lane" % (variant, scratch)
+        assert vgpr <= 72, "%s needs %d VGPRs (budget 72 = 7 waves per SIMD)" % (variant, vgpr)
+        checked += 1
+    assert checked == 2
