@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="sub-batches tracked on concurrent HIP streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="build every pyramid in order on the tracking stream")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-stream side measurements")
     ap.add_argument("--pcie-steps", type=int, default=4, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     return ap.parse_args()
@@ -118,8 +119,13 @@ def main():
     batch = dvo.Batch(B, K, W, H, levels, culls, cfg=cfg)
     poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
 
-    def push(bt, k, out=None):
+    def push(bt, k, out=None, last=False):
+        # frames are resident and complete: the pyramid of frame k+1 is built on the library's side stream while frame k tracks
+        # (dvo_batch_prefetch_device; --no-prefetch restores the strictly in-order form)
         f = ring_index(k, F)
+        if not a.no_prefetch and k >= 1 and not last:
+            fn = ring_index(k + 1, F)
+            bt.prefetch_device(gray[fn].data_ptr(), depth[fn].data_ptr(), sigma[fn].data_ptr())
         bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
         if out is not None:
             bt.copy_poses_device(out.data_ptr())
@@ -136,7 +142,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        push(batch, 1 + a.warmup + k, poses_out[k])
+        push(batch, 1 + a.warmup + k, poses_out[k], last=(k == a.steps - 1))
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -223,7 +229,7 @@ def main():
             push(pb, 1 + k)
         pb.profile(reset=True)
         for k in range(a.steps):
-            push(pb, 1 + a.warmup + k)
+            push(pb, 1 + a.warmup + k, last=(k == a.steps - 1))
         pr = pb.profile()
         top_ms, top_px = pb.probe_gn(levels - 1, 20)
         pb.close()

@@ -205,6 +205,12 @@ int dvo_batch_push_device(dvo_batch* b, const float* gray, const float* depth, c
     return b->impl.push_device(gray, depth, sigma);
 }
 
+int dvo_batch_prefetch_device(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    return b->impl.prefetch_device(gray, depth, sigma);
+}
+
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
 {
     if (!b || !gray || !depth || !sigma) return DVO_ERR_BAD_ARGUMENT;
@@ -287,7 +293,7 @@ int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, u
     if (B.cur < 0 || !B.have_poses) return DVO_ERR_NOT_READY;
     DVO_TRY(select_device(B.device));
     // obj = the newest frame set, ref = the one before it: exactly the operands of the last track() call
-    const GnArgs ga = B.trk.gn_args(B.fs[B.cur], B.fs[B.cur ^ 1], level, nullptr, 1);
+    const GnArgs ga = B.trk.gn_args(B.fs[B.cur], B.fs[B.prev], level, nullptr, 1);
     hipEvent_t e0, e1;
     DVO_HIP(hipEventCreate(&e0));
     DVO_HIP(hipEventCreate(&e1));

@@ -696,6 +696,9 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16])
 // ------------------------------------------------------------------------------------------------ batch
 Batch::~Batch()
 {
+    if (pstream) { (void)hipStreamSynchronize(pstream); (void)hipStreamDestroy(pstream); }
+    if (ev_last_track) (void)hipEventDestroy(ev_last_track);
+    for (int i = 0; i < 3; i++) if (ev_built[i]) (void)hipEventDestroy(ev_built[i]);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -708,9 +711,34 @@ int Batch::init(int n, const float K9[9], int w, int h, int levels, int culls, c
     if (cfg.stream) stream = (hipStream_t)cfg.stream;
     else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
     DVO_TRY(make_geometry(K9, w, h, levels, culls, g));
-    DVO_TRY(fs[0].alloc(g, n, cfg));
-    DVO_TRY(fs[1].alloc(g, n, cfg));
+    for (int i = 0; i < 3; i++) DVO_TRY(fs[i].alloc(g, n, cfg));
     DVO_TRY(trk.init(g, n, cfg));
+    {   // lowest priority: the pyramid build should fill what the tracker leaves idle, not compete with it
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        DVO_HIP(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, lo));
+    }
+    DVO_HIP(hipEventCreateWithFlags(&ev_last_track, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) DVO_HIP(hipEventCreateWithFlags(&ev_built[i], hipEventDisableTiming));
+    return DVO_OK;
+}
+
+// Builds the pyramids of a frame that will be handed to push_device later (call order per step: prefetch(k+1); push(k)) on the
+// side stream.  The set it builds into may be the reference of the tracking queued last: the build waits for that tracking --
+// not for anything queued afterwards -- and then runs beside the tracking of frame k.
+int Batch::prefetch_device(const float* gray, const float* depth, const float* sigma)
+{
+    if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const int slot = free_slot();
+    if (npre >= 2 || slot < 0) { set_error("dvo_batch_prefetch_device: two prefetched frames are already waiting for their push"); return DVO_ERR_NOT_READY; }
+    if (tracked_once) DVO_HIP(hipStreamWaitEvent(pstream, ev_last_track, 0));
+    build_pyramid(fs[slot], gray, depth, sigma, pstream, /*keep_sigma=*/false);
+    DVO_HIP(hipEventRecord(ev_built[slot], pstream));
+    preq[npre] = slot;
+    pre_key[npre][0] = gray; pre_key[npre][1] = depth; pre_key[npre][2] = sigma;
+    npre++;
+    DVO_HIP(hipGetLastError());
     return DVO_OK;
 }
 
@@ -718,12 +746,25 @@ int Batch::push_device(const float* gray, const float* depth, const float* sigma
 {
     if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
-    const int target = (cur < 0) ? 0 : (cur ^ 1);
-    build_pyramid(fs[target], gray, depth, sigma, stream, /*keep_sigma=*/false);  // Frame(gray,depth,sigma,K,levels,culls)
+    int target;
+    if (npre > 0 && pre_key[0][0] == gray && pre_key[0][1] == depth && pre_key[0][2] == sigma) {
+        target = preq[0];                                   // built by prefetch_device: the tracker waits for that build
+        DVO_HIP(hipStreamWaitEvent(stream, ev_built[target], 0));
+        preq[0] = preq[1];
+        for (int i = 0; i < 3; i++) pre_key[0][i] = pre_key[1][i];
+        npre--;
+    } else {
+        target = (cur < 0 && npre == 0) ? 0 : free_slot();
+        if (target < 0) { set_error("dvo_batch_push_device: the frames prefetched must be pushed first, in order"); return DVO_ERR_BAD_ARGUMENT; }
+        build_pyramid(fs[target], gray, depth, sigma, stream, /*keep_sigma=*/false);  // Frame(gray,depth,sigma,K,levels,culls)
+    }
     if (cur >= 0) {
         DVO_TRY(trk.track(fs[target], fs[cur], stream));    // system.hpp:88
+        DVO_HIP(hipEventRecord(ev_last_track, stream));
+        tracked_once = true;
         have_poses = true;
     }
+    prev = cur;
     cur = target;                                           // system.hpp:91
     DVO_HIP(hipGetLastError());
     return DVO_OK;

@@ -167,12 +167,31 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
     bool own_stream = false;
     Geometry g;
     Tracker trk;
-    FrameSet fs[2];
-    int cur = -1;           // index of the reference frame set (-1: none yet)
+    // Three frame sets: the reference (cur), the frame being tracked against it, and one that the pyramid of a LATER frame can
+    // be built into on a low-priority side stream while tracking runs (prefetch_device): k_pyramid is HBM bound, the tracker
+    // mostly VALU / latency bound.
+    FrameSet fs[3];
+    int cur = -1;           // frame set of the newest tracked frame = reference of the next (-1: none yet)
+    int prev = -1;          // its own reference (probes)
+    // prefetched frame sets waiting for their push_device, oldest first.  In steady state two are outstanding at the moment
+    // prefetch_device is called: "prefetch(k+1); push(k)" finds frame k (prefetched one step earlier) still waiting.
+    int preq[2] = {-1, -1};
+    int npre = 0;
+    const float* pre_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipStream_t pstream = nullptr;
+    hipEvent_t ev_last_track = nullptr, ev_built[3] = {nullptr, nullptr, nullptr};
+    bool tracked_once = false;
     bool have_poses = false;
     DevBuf in_gray, in_depth, in_sigma;  // staging for push_host
     ~Batch();
     int init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c);
+    int free_slot() const  // a frame set that is neither the reference nor waiting prefetched (-1: none)
+    {
+        for (int i = 0; i < 3; i++)
+            if (i != cur && !(npre > 0 && preq[0] == i) && !(npre > 1 && preq[1] == i)) return i;
+        return -1;
+    }
+    int prefetch_device(const float* gray, const float* depth, const float* sigma);
     int push_device(const float* gray, const float* depth, const float* sigma);
 };
 

@@ -67,7 +67,7 @@ EXPORTS = [
     "dvo_vo_odometrize_depth", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
     "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
-    "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
+    "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
     "dvo_op_propagate", "dvo_op_regularize", "dvo_op_depth_update", "dvo_op_se3_exp", "dvo_op_se3_log",
     "dvo_op_se3_concatenate",
@@ -484,6 +484,10 @@ class Batch:
     def push_device(self, gray_ptr, depth_ptr, sigma_ptr):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()) to [n_seq, H, W] float32."""
         _check(lib().dvo_batch_push_device(self._p, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), C.c_void_p(sigma_ptr)))
+
+    def prefetch_device(self, gray_ptr, depth_ptr, sigma_ptr):
+        """Build the pyramids of the frame that the NEXT push_device will receive, on a side stream (the buffers must be complete)."""
+        _check(lib().dvo_batch_prefetch_device(self._p, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), C.c_void_p(sigma_ptr)))
 
     def push_host(self, gray, depth, sigma):
         g = f32(gray); d = f32(depth); s = f32(sigma)

@@ -125,6 +125,13 @@ int dvo_batch_destroy(dvo_batch* b);
  * new frames, tracks them against the previous frames (Tracker::track, tracker.cpp:22-85) and makes them the
  * new reference.  The first call only stores the reference.  Asynchronous on the handle's stream. */
 int dvo_batch_push_device(dvo_batch* b, const float* gray_dev, const float* depth_dev, const float* sigma_dev);
+/* Optional look-ahead: build the pyramids of a frame that will be pushed later on a library-owned, low-priority side
+ * stream, so that this HBM-bound pass runs beside the tracking of the frame pushed in between.  Call order per step:
+ *   dvo_batch_prefetch_device(frame k+1); dvo_batch_push_device(frame k);
+ * The same three pointers must later be handed to dvo_batch_push_device, in the order the frames were prefetched; at most
+ * two may be waiting.  The buffers must be complete when this is called: the read is NOT ordered against the caller's
+ * stream. */
+int dvo_batch_prefetch_device(dvo_batch* b, const float* gray_dev, const float* depth_dev, const float* sigma_dev);
 /* same, from host memory (adds the H2D copies) */
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma);
 /* relative twists [n_seq][6] and 4x4 relative poses [n_seq][16] of the last push (synchronises). NULL = skip */

@@ -481,3 +481,34 @@ def test_adaptive_schedule_changes_no_result():
     assert res[0][1] == res[1][1]
     np.testing.assert_array_equal(res[0][2], res[1][2])
     assert res[0][3] == res[1][3]
+
+
+def test_batch_prefetch_changes_no_result():
+    """dvo_batch_prefetch_device only moves the pyramid build of the next frame onto a side stream: poses are bit-identical."""
+    import torch
+    g, d, s, _ = frames(4, sigma=0.1)
+    B = 12
+    dev = torch.device("cuda", 0)
+    tg = [torch.from_numpy(np.stack([g[(b + f) % 4] for b in range(B)])).to(dev) for f in range(4)]
+    td = [torch.from_numpy(np.stack([d[(b + f) % 4] for b in range(B)])).to(dev) for f in range(4)]
+    ts = [torch.from_numpy(np.stack([s[(b + f) % 4] for b in range(B)])).to(dev) for f in range(4)]
+    torch.cuda.synchronize()
+    res = []
+    for prefetch in (False, True):
+        bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        out = []
+        for k in range(6):
+            f = k % 4
+            if prefetch and k >= 1 and k < 5:
+                fn = (k + 1) % 4
+                bt.prefetch_device(tg[fn].data_ptr(), td[fn].data_ptr(), ts[fn].data_ptr())
+            bt.push_device(tg[f].data_ptr(), td[f].data_ptr(), ts[f].data_ptr())
+            if k >= 1:
+                out.append(bt.last_poses()[0].copy())
+        res.append(np.stack(out))
+        with pytest.raises(dvo.DvoError):   # no more than two frames may wait prefetched
+            for f in range(3):
+                bt.prefetch_device(tg[f].data_ptr(), td[f].data_ptr(), ts[f].data_ptr())
+        bt.close()
+    assert np.abs(res[0]).max() > 1e-4
+    np.testing.assert_array_equal(res[0], res[1])
