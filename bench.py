@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="sequences tracked concurrently per GPU (0 = 4096 for syn640, 16 for syn1080)")
+    ap.add_argument("--batch", type=int, default=0, help="sequences tracked concurrently per GPU (0 = 4096 for syn640, 128 for syn1080)")
     ap.add_argument("--frames", type=int, default=6, help="distinct frames per sequence kept in HBM (ping-pong order)")
     ap.add_argument("--workload", default="syn640", choices=["syn640", "syn1080"])
     ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
@@ -87,7 +87,7 @@ def main():
         if a.fixed_iters == 0:
             a.fixed_iters = 10
     if a.batch <= 0:
-        a.batch = 4096 if a.workload == "syn640" else 16  # ~115 GB of the 288 GB: inputs 91 GB + two pyramid sets
+        a.batch = 4096 if a.workload == "syn640" else 128  # ~115 GB of the 288 GB: inputs 91 GB + two pyramid sets
     B, F = a.batch, max(2, a.frames)
 
     # ---- synthetic sequences rendered straight into HBM: [F][B][H][W] --------------------------------
