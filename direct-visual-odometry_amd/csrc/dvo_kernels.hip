@@ -293,7 +293,7 @@ __device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, 
     gy = blend4(t.rc.y - t.ra.x, t.rc.z - t.ra.y, t.rd.x - t.rb.y, t.rd.y - t.rb.z, hx, vy);
     const float probe = (I2 + gx) + gy;  // a NaN tap (fminf skips NaN) poisons at least one of the three
     decidable = (mn > kInvalid) & (probe == probe);
-    valid = !(is_invalid(I2) | is_invalid(gx) | is_invalid(gy));
+    valid = ((int)is_invalid(I2) | (int)is_invalid(gx) | (int)is_invalid(gy)) == 0;  // bitwise on purpose: no short-circuit branches
 }
 
 // k_prep_ref: per-pixel constants of a reference frame (all levels, one launch): iz = 1/depth and
