@@ -91,8 +91,8 @@ struct SolveArgs {
 // Tile geometry of k_track_gn: the single source of tile counts for host and device code.
 //  * raster tiles: 256 * ppt consecutive pixels (any size; tiles outside the crop rows are not live);
 //  * 2-D tiles (ppt = 4): TW = 2^shift columns x (64 / TW) * 16 rows, lane = (column, row-in-wave), wave w owns pixel rows
-//    w*4 .. w*4+3 of the lane's row set.  Used when the width is a multiple of 64 (and the level has no crop window):
-//    64 x 16 tiles over the whole image -- only tiles on the image border hold border pixels.
+//    w*4 .. w*4+3 of the lane's row set.  Used when the width is a multiple of 64, 32 or 16 (64 x 16, 32 x 32, 16 x 64 tiles),
+//    the level has no crop window and is at least two tiles tall: only tiles on the image border hold border pixels.
 struct GnTiling {
     int t2d = 0, shift = 6, tiles_x = 1, x_org = 0, y_org = 0;
     int count = 1;                        // tiles (= partial rows) per sequence
@@ -106,11 +106,17 @@ inline GnTiling gn_tiling(int w, int h, int ppt, int crop)
     // (Tried: 32 x 32 tiles laid over the crop window [20,140] x [20,100] of the crop level, so that no tile touches the image
     // border and nothing outside the window is evaluated.  No measurable change -- that level's launches are latency chains,
     // not work -- so the crop level keeps raster tiles; x_org / y_org / shift stay general for it.)
-    if (ppt == 4 && !crop && w >= 64 && (w % 64) == 0) {
-        t.t2d = 1; t.shift = 6; t.tiles_x = w / 64;
-        t.count = t.tiles_x * ((h + 15) / 16);
-        t.live_first = 0; t.live_count = t.count; t.live_pixels = npix;
-        return t;
+    if (ppt == 4 && !crop && w >= 16 && (w % 16) == 0) {
+        // the widest power-of-two tile width (<= 64) that divides the level width; rows per tile = (64 / TW) * 16, and the
+        // tile must not be taller than about half the image (else every tile touches the top and bottom border anyway)
+        const int shift = (w % 64) == 0 ? 6 : ((w % 32) == 0 ? 5 : 4);
+        const int rows = (64 >> shift) * 16;
+        if (rows * 2 <= h) {
+            t.t2d = 1; t.shift = shift; t.tiles_x = w >> shift;
+            t.count = t.tiles_x * ((h + rows - 1) / rows);
+            t.live_first = 0; t.live_count = t.count; t.live_pixels = npix;
+            return t;
+        }
     }
     const int T = 256 * ppt;
     t.count = (npix + T - 1) / T;
