@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
     float raw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 3; m++)
-        if (a.src[m] != nullptr) raw[m] = a.src[m][src_off];  // the three loads are in flight together
+        if (a.src[m] != nullptr) raw[m] = __builtin_nontemporal_load(a.src[m] + src_off);  // read once: streamed past the caches; the three loads are in flight together
     // the reference-frame constants of k_prep_ref, written while depth and sigma are in registers (needs both maps)
     const bool prep = a.iz[0] != nullptr && a.src[1] != nullptr && a.src[2] != nullptr;
     for (int t = 0; t < a.levels; t++) {
@@ -161,11 +161,11 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
         for (int m = 0; m < 3; m++) {
             // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
             val[m] = (t == 0 && a.culls == 0) ? raw[m] : pass_valid(raw[m]);
-            if (a.src[m] != nullptr && a.dst[m][l] != nullptr) a.dst[m][l][o] = val[m];  // (a map may be consumed without being kept)
+            if (a.src[m] != nullptr && a.dst[m][l] != nullptr) __builtin_nontemporal_store(val[m], a.dst[m][l] + o);  // (a map may be consumed without being kept; next read: a whole tracking step later)
         }
         if (prep) {
-            a.iz[l][o] = 1.0f / val[1];
-            a.wgt[l][o] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]);
+            __builtin_nontemporal_store(1.0f / val[1], a.iz[l] + o);
+            __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]), a.wgt[l] + o);
         }
     }
 }
