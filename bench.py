@@ -250,7 +250,7 @@ def main():
             # The kernel's real ceiling is FP32 VALU issue, not HBM: at I VALU instructions per pixel (SQ_INSTS_VALU of the
             # committed PMC run) the chip cannot exceed lanes x clock / I pixels per second, whatever the memory system does.
             import glob
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*k_track_gn_pmc.txt")), reverse=True):
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*k_track_gn_pmc.txt")), key=_natural, reverse=True):
                 valu = waves = None
                 for line in open(fn):  # the last dispatch block of the file is the finest-level probe launch
                     t = line.split()
@@ -266,7 +266,7 @@ def main():
                                                        "source": "profiles/" + os.path.basename(fn)}
                     break
             if a.workload == "syn640" and a.fixed_iters == 0:
-                for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+                for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), key=_natural, reverse=True):
                     with open(fn) as fh:
                         tr = json.load(fh)
                     if tr.get("kernel") == "k_track_gn" and tr.get("sequences_per_gpu") == B:
@@ -339,6 +339,12 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _natural(path):
+    """Sort key that orders r01_v9 before r01_v10 (newest profile summary last)."""
+    import re
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
 
 
 def _cpu_model():
