@@ -122,3 +122,60 @@ def test_hot_kernel_fits_its_register_budget():
         assert vgpr <= 72, "%s needs %d VGPRs (budget 72 = 7 waves per SIMD)" % (variant, vgpr)
         checked += 1
     assert checked == 2
+
+
+def test_tile_geometry_covers_every_pixel_once():
+    """gn_tiling() (csrc/dvo_kernels.h) is the single source of tile counts for host and device.  For a spread of level shapes:
+    every pixel that can contribute (inside the crop window on a crop level) belongs to exactly one live tile."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = r'''
+#include "dvo_kernels.h"
+#include <cstdio>
+#include <vector>
+using namespace dvo;
+int main() {
+    const int shapes[][3] = {{320,240,0},{160,120,1},{160,120,0},{80,60,0},{40,30,0},{1920,1080,0},{960,540,0},{480,270,0},{240,135,0},
+                             {120,67,0},{322,243,0},{37,29,0},{64,16,0},{64,48,0},{16,200,0},{150,110,1},{30,25,1}};
+    for (auto& sh : shapes) for (int ppt : {1, 2, 4, 8}) {
+        const int w = sh[0], h = sh[1], crop = sh[2];
+        const GnTiling t = gn_tiling(w, h, ppt, crop);
+        if (t.live_first < 0 || t.live_count < 0 || t.live_first + t.live_count > t.count) { printf("bad live range %d %d %d\n", w, h, ppt); return 1; }
+        std::vector<int> hits((size_t)w * h, 0);
+        for (int b = t.live_first; b < t.live_first + t.live_count; b++) {
+            if (t.t2d) {
+                const int tw = 1 << t.shift, rw = 64 >> t.shift, R = rw * 4 * ppt;
+                const int ty = b / t.tiles_x, tx = b % t.tiles_x;
+                for (int y = t.y_org + ty * R; y < t.y_org + ty * R + R; y++)
+                    for (int x = t.x_org + tx * tw; x < t.x_org + tx * tw + tw; x++)
+                        if (x < w && y < h) hits[(size_t)y * w + x]++;
+            } else {
+                for (long long i = (long long)b * 256 * ppt; i < (long long)(b + 1) * 256 * ppt; i++)
+                    if (i < (long long)w * h) hits[(size_t)i]++;
+            }
+        }
+        long long live = 0;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            const bool need = !crop || (x >= 20 && x <= 140 && y >= 20 && y <= 100);
+            const int c = hits[(size_t)y * w + x];
+            if (c > 1 || (need && c != 1)) { printf("pixel (%d,%d) of %dx%d ppt %d crop %d covered %d times\n", x, y, w, h, ppt, crop, c); return 1; }
+            live += c;
+        }
+        if (live != t.live_pixels) { printf("live_pixels %lld != %lld for %dx%d ppt %d crop %d\n", t.live_pixels, live, w, h, ppt, crop); return 1; }
+    }
+    printf("ok\n");
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        cpp = os.path.join(td, "t.cpp")
+        open(cpp, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run([hipcc, "-std=c++17", "-x", "hip", "--cuda-host-only", "-I", os.path.join(ROOT, "direct-visual-odometry_amd", "csrc"),
+                        cpp, "-o", exe], check=True, capture_output=True, timeout=600)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
