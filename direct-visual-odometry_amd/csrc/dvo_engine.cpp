@@ -200,6 +200,15 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         set_error("iteration counts must be within [1, DVO_MAX_ITERATIONS]");
         return DVO_ERR_BAD_ARGUMENT;
     }
+    for (int l = 0; l < g.levels; l++)
+        if (g.w[l] < 4 || g.h[l] < 4) {  // k_track_gn's parked lanes gather the 4 x 4 taps around (1, 1): every level must hold them
+            set_error("pyramid level smaller than 4 x 4 pixels");
+            return DVO_ERR_BAD_ARGUMENT;
+        }
+    if ((unsigned long long)n_seq * (unsigned long long)g.w[g.top()] * g.h[g.top()] / 256ull >= (1ull << 31)) {
+        set_error("too many sequences for one launch grid");
+        return DVO_ERR_BAD_ARGUMENT;
+    }
     size_t max_part = 0;
     // gn_use_lds_patch: -1 = auto, 0 = global gathers, N > 0 = LDS patch with margin N.  Auto is the global-gather
     // kernel: measured on MI355X (profiles/r01_gn_variants.md) the LDS-staged variant is 10-15 % slower.
@@ -264,7 +273,9 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
     adaptive = cfg.track_adaptive >= 0 && n_sub == 1 && tile_margin == 0 && cfg.fixed_iterations <= 0;
     if (adaptive) {
         const size_t words = 2 * (size_t)DVO_MAX_LEVELS * DVO_MAX_ITERATIONS;
-        DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_progress), words * sizeof(int), hipHostMallocMapped | hipHostMallocNonCoherent));
+        // fine-grained (coherent) host memory: the device publishes a word with a system-scope release store and the host
+        // sees it without waiting for a kernel boundary (coarse-grained memory only guarantees that after a host sync)
+        DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_progress), words * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
         memset(h_progress, 0, words * sizeof(int));
         DVO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_progress), h_progress, 0));
     }
@@ -353,7 +364,11 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 volatile int* pw = prog_h + level * DVO_MAX_ITERATIONS + (it - ahead);
                 long spins = 0;
                 while (*pw == 0) {
-                    if (++spins > 2000000000L) { set_error("adaptive schedule: the GPU made no progress"); return DVO_ERR_HIP; }
+                    if (++spins > 2000000000L) {
+                        (void)hipStreamSynchronize(s);  // nothing may be left writing the progress words / state when we return
+                        set_error("adaptive schedule: the GPU made no progress");
+                        return DVO_ERR_HIP;
+                    }
                     __builtin_ia32_pause();
                 }
                 if (*pw - 1 == 0) break;

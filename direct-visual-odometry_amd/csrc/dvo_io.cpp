@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <new>
+#include <stdexcept>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -30,7 +32,24 @@ struct PngImage {
     std::vector<unsigned char> data;  // 8-bit: bytes; 16-bit: host-endian uint16
 };
 
+static int png_decode_impl(const std::string& path, PngImage& img, bool header_only);
+
+// The decoder trusts nothing in the file (a crafted PNG in a dataset directory must not take the process down): sizes are
+// bounded before any allocation and no C++ exception crosses the extern "C" boundary.
 static int png_decode(const std::string& path, PngImage& img, bool header_only)
+{
+    try {
+        return png_decode_impl(path, img, header_only);
+    } catch (const std::bad_alloc&) {
+        set_error(path + ": out of memory while decoding");
+        return DVO_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        set_error(path + ": " + e.what());
+        return DVO_ERR_BAD_ARGUMENT;
+    }
+}
+
+static int png_decode_impl(const std::string& path, PngImage& img, bool header_only)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) { set_error("cannot open " + path); return DVO_ERR_BAD_ARGUMENT; }
@@ -40,13 +59,19 @@ static int png_decode(const std::string& path, PngImage& img, bool header_only)
     size_t pos = 8;
     std::vector<unsigned char> idat;
     int color_type = -1, interlace = 0;
+    bool first = true;
     while (pos + 12 <= buf.size()) {
         const uint32_t len = be32(&buf[pos]);
         const char* type = reinterpret_cast<const char*>(&buf[pos + 4]);
         if (pos + 12 + (size_t)len > buf.size()) { set_error(path + ": truncated chunk"); return DVO_ERR_BAD_ARGUMENT; }
         const unsigned char* d = &buf[pos + 8];
+        if (first != (memcmp(type, "IHDR", 4) == 0)) { set_error(path + ": IHDR must be the first chunk, once"); return DVO_ERR_BAD_ARGUMENT; }
+        first = false;
         if (!memcmp(type, "IHDR", 4)) {
-            img.w = (int)be32(d); img.h = (int)be32(d + 4);
+            if (len != 13) { set_error(path + ": bad IHDR length"); return DVO_ERR_BAD_ARGUMENT; }
+            const uint32_t uw = be32(d), uh = be32(d + 4);
+            if (uw == 0 || uh == 0 || uw > 16384u || uh > 16384u) { set_error(path + ": image size outside [1, 16384]"); return DVO_ERR_BAD_ARGUMENT; }
+            img.w = (int)uw; img.h = (int)uh;
             img.bit_depth = d[8]; color_type = d[9]; interlace = d[12];
         } else if (!memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), d, d + len);

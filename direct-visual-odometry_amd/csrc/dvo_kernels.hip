@@ -137,9 +137,10 @@ __device__ __forceinline__ void split_index(int i, int w, float inv_w, int& x, i
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
 {
-    const int seq = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
+    const unsigned bps = ((unsigned)(tw * th) + 255u) >> 8;  // workgroups per sequence (the sequence index lives in grid.x: no 65535 limit)
+    const int seq = (int)(blockIdx.x / bps);
+    const int i = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + threadIdx.x;
     if (i >= tw * th) return;
     int x, y;
     split_index(i, tw, a.inv_tw, x, y);
@@ -684,7 +685,10 @@ __global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
     const int n_in = a.list_in ? a.list_in[0] : a.n_seq;  // sequences this launch handles
     // progress word in mapped host memory (adaptive schedule, Tracker::track): "iteration reached, n sequences were active".
     // Kept out of k_track_gn on purpose: that kernel sits exactly at its 72-VGPR budget and one more live value makes it spill.
-    if (a.progress && blockIdx.x == 0 && threadIdx.x == 0) *a.progress = n_in + 1;
+    // Fine-grained host memory + a system-scope atomic store (sc0 sc1: written through, never parked in L2).  Relaxed on purpose:
+    // the word is a hint for the host's launch schedule, no data is read on its strength, and a system-scope RELEASE here would
+    // write back every dirty L2 line (the partial rows k_track_gn has just produced) once per launch.
+    if (a.progress && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.progress, n_in + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)blockIdx.x * DVO_SOLVE_SEQ >= n_in) return;
     // Everything this kernel needs from memory is requested up front (a fresh kernel starts with cold caches: each
     // dependent round trip costs ~2 us): lanes 0..7 the state of their sequence, every team its partial rows.
@@ -1268,7 +1272,7 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s)
 {
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
-    hipLaunchKernelGGL(k_pyramid, dim3(cdiv(tw * th, 256), n_seq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pyramid, dim3(cdiv(tw * th, 256) * (unsigned)n_seq), dim3(256), 0, s, a);
 }
 
 void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s)

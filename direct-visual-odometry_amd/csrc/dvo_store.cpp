@@ -101,14 +101,14 @@ int dvo_vo_load(dvo_vo* vo, const char* path)
         for (int l = 0; l < g.levels && ok; l++) {
             buf.resize((size_t)g.w[l] * g.h[l]);
             ok = get(f, buf.data(), buf.size() * 4);
-            if (ok) DVO_HIP(hipMemcpy(k->fs.gray[l], buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+            if (ok) { const int hs = check_hip(hipMemcpy(k->fs.gray[l], buf.data(), buf.size() * 4, hipMemcpyHostToDevice), "hipMemcpy(keyframe gray)"); if (hs != DVO_OK) { fclose(f); return hs; } }
         }
         const int T = g.top();
         buf.resize((size_t)g.w[T] * g.h[T]);
         float* maps[3] = {k->fs.depth[T], k->fs.sigma[T], k->age.as<float>()};
         for (int m = 0; m < 3 && ok; m++) {
             ok = get(f, buf.data(), buf.size() * 4);
-            if (ok) DVO_HIP(hipMemcpy(maps[m], buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+            if (ok) { const int hs = check_hip(hipMemcpy(maps[m], buf.data(), buf.size() * 4, hipMemcpyHostToDevice), "hipMemcpy(keyframe map)"); if (hs != DVO_OK) { fclose(f); return hs; } }
         }
         if (ok) {
             redecimate(k->fs, k->fs.depth[T], k->fs.sigma[T], v.stream);  // lower levels + iz / wgt, as Frame::updateDepthSigma

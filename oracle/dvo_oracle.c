@@ -11,6 +11,16 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Row-parallel execution of the forEach bodies (cv::Mat::forEach runs them on OpenCV's thread pool: optimize.cpp:28,
+ * transform.cpp:39, convert.cpp:48,61).  Default 1 thread = the sequential raster order of D7, bit for bit; n > 1 is used by
+ * bench.py's all-core CPU baseline only (per-thread partial sums combined in thread order: deterministic for a fixed n). */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+int  orc_get_threads(void) { return g_threads; }
 
 /* ------------------------------------------------------------------------ */
 /* include/math/util.hpp:6-32                                                */
@@ -278,6 +288,7 @@ void orc_cull_intrinsic(const float K[9], int times, float out[9])
 void orc_gradiate(const float* img, int w, int h, int xdir, float* out)
 { /* convert.cpp:41-75 */
     for (int i = 0; i < w * h; i++) out[i] = ORC_INVALID;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float a, b;
@@ -382,6 +393,7 @@ void orc_warp(const float Rt[12], float px, float py, float d, const float K[9],
 
 void orc_warp_image(const float xi[6], const float* gray, const float* depth, int w, int h, const float K[9], float* out)
 { /* transform.cpp:35-51; the reference re-derives exp(-xi) per pixel (transform.cpp:13-14) */
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const int i = y * w + x;
@@ -629,40 +641,61 @@ static void optimize_impl(const float* obj_gray, const float* ref_gray, const fl
         warped = (float*)malloc(sizeof(float) * (size_t)n);
         orc_warp_image(xi, ref_gray, ref_depth, w, h, K, warped);
     }
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            const int i = y * w + x;
-            float I2, J[6], r, rw, Rpix[12];
-            const float* P = Rt;
-            if (variant == 1) {
-                I2 = warped[i];
-                orc_pose_from_xi(xi, -1.0f, Rpix); /* optimize.cpp:51 -> per-pixel se3::exp */
-                P = Rpix;
-            } else {
-                const float d = ref_depth[i];
-                if (is_epsilon(d)) {
-                    I2 = ORC_INVALID;
+    /* The per-pixel lambda of optimize.cpp:28-90.  One thread (the default): plain raster order.  g_threads > 1: rows are dealt
+     * to threads in contiguous blocks, every thread sums into its own partial, partials are added in thread order. */
+    const int nthr = g_threads > 1 ? g_threads : 1;
+    orc_outcome* part = (orc_outcome*)calloc((size_t)nthr, sizeof(orc_outcome));
+#pragma omp parallel num_threads(nthr) if (nthr > 1)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        orc_outcome* acc = &part[tid];
+#pragma omp for schedule(static)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int i = y * w + x;
+                float I2, J[6], r, rw, Rpix[12];
+                const float* P = Rt;
+                if (variant == 1) {
+                    I2 = warped[i];
+                    orc_pose_from_xi(xi, -1.0f, Rpix); /* optimize.cpp:51 -> per-pixel se3::exp */
+                    P = Rpix;
                 } else {
-                    float p[2];
-                    orc_warp(Rt, (float)x, (float)y, d, K, p);
-                    I2 = orc_get_subpixel(ref_gray, w, h, p[0], p[1]);
+                    const float d = ref_depth[i];
+                    if (is_epsilon(d)) {
+                        I2 = ORC_INVALID;
+                    } else {
+                        float p[2];
+                        orc_warp(Rt, (float)x, (float)y, d, K, p);
+                        I2 = orc_get_subpixel(ref_gray, w, h, p[0], p[1]);
+                    }
+                }
+                if (!optimize_pixel(obj_gray, gradx, grady, ref_depth, ref_sigma, w, h, K, P, I2, x, y, level, crop_enable, step, J, &r, &rw))
+                    continue;
+                acc->n_valid++;
+                if (mask) mask[i] = 1;
+                acc->sum_r2 += (double)r * (double)r;
+                int k = 0;
+                for (int a = 0; a < 6; a++) {
+                    for (int b = a; b < 6; b++) acc->H[k++] += (double)J[a] * (double)J[b];
+                    acc->g[a] += (double)J[a] * (double)rw;
+                }
+                if (variant == 1) {
+                    for (int a = 0; a < 6; a++) A[6 * i + a] = J[a];
+                    B[i] = rw;
                 }
             }
-            if (!optimize_pixel(obj_gray, gradx, grady, ref_depth, ref_sigma, w, h, K, P, I2, x, y, level, crop_enable, step, J, &r, &rw))
-                continue;
-            out->n_valid++;
-            if (mask) mask[i] = 1;
-            out->sum_r2 += (double)r * (double)r;
-            int k = 0;
-            for (int a = 0; a < 6; a++) {
-                for (int b = a; b < 6; b++) out->H[k++] += (double)J[a] * (double)J[b];
-                out->g[a] += (double)J[a] * (double)rw;
-            }
-            if (variant == 1) {
-                for (int a = 0; a < 6; a++) A[6 * i + a] = J[a];
-                B[i] = rw;
-            }
-        }
+    }
+    *out = part[0];  /* (one thread: exactly the sequential sums) */
+    for (int t = 1; t < nthr; t++) {
+        out->n_valid += part[t].n_valid;
+        out->sum_r2 += part[t].sum_r2;
+        for (int k = 0; k < 21; k++) out->H[k] += part[t].H[k];
+        for (int k = 0; k < 6; k++) out->g[k] += part[t].g[k];
+    }
+    free(part);
     if (out->n_valid == 0) { /* optimize.cpp:92-93 */
         out->residual = -1.0f;
     } else {

@@ -54,6 +54,11 @@ extern "C" {
 #define ORC_MAX_LEVELS 8
 #define ORC_MAX_ITER 15
 
+/* Threads used by the forEach bodies (gradiate, warpImage, the optimize lambda): 1 (default) = sequential raster order, the
+ * oracle proper; n > 1 = row-parallel as cv::Mat::forEach, for bench.py's all-core CPU baseline. */
+void orc_set_threads(int n);
+int  orc_get_threads(void);
+
 /* ---- math/se3.cpp ---------------------------------------------------- */
 void orc_se3_exp(const float xi[6], float T[16]);               /* se3.cpp:70-98  (double inside, D2) */
 void orc_se3_log(const float T[16], float xi[6]);               /* se3.cpp:101-124 */

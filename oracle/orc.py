@@ -84,6 +84,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Threads of the forEach bodies: 1 = the sequential oracle; n > 1 = row-parallel (cv::Mat::forEach), bench baseline only."""
+    lib().orc_set_threads(int(n))
+
+
 def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

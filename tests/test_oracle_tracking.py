@@ -223,3 +223,27 @@ def test_visual_odometry_depth_mode_relative_pose():
     ref = orc.OFrame(g[0], d[0], s[0], K640, 4, 1); obj = orc.OFrame(g[1], d[1], s[1], K640, 4, 1)
     xi, _ = orc.track(obj, ref)
     np.testing.assert_array_equal(T1, orc.se3_exp(xi))                 # returns exp(relative_xi), system.hpp:92
+
+
+def test_row_parallel_oracle_agrees_with_the_sequential_one():
+    """orc.set_threads(n): the forEach bodies run row-parallel (what cv::Mat::forEach does, optimize.cpp:28) for bench.py's
+    all-core CPU baseline.  Pixel selection is identical; sums differ only by the association order of per-thread partials."""
+    from util import frames, K640
+    g, d, s, _ = frames()
+    ref = orc.OFrame(g[0], d[0], s[0], K640, 4, 1)
+    obj = orc.OFrame(g[1], d[1], s[1], K640, 4, 1)
+    xi = np.array([0.002, -0.001, 0.003, 0.002, -0.001, 0.001], np.float32)
+    res = []
+    try:
+        for n in (1, 4):
+            orc.set_threads(n)
+            res.append([orc.optimize(obj.gray(3), ref.gray(3), ref.depth(3), ref.sigma(3), ref.K(3), xi, 3, variant=v, want_mask=True)
+                        for v in (0, 1)])
+    finally:
+        orc.set_threads(1)
+    for v in (0, 1):
+        a, b = res[0][v], res[1][v]
+        np.testing.assert_array_equal(a["mask"], b["mask"])
+        assert a["n_valid"] == b["n_valid"]
+        np.testing.assert_allclose(b["H"], a["H"], rtol=1e-12)
+        np.testing.assert_allclose(b["xi_update"], a["xi_update"], rtol=1e-5, atol=1e-9)
