@@ -51,3 +51,24 @@ def ingest_np(rgb, d16, scale=1.0 / 5000.0):
     sigma = np.where(d16 > 0, np.float32(0.1), np.float32(1.0)).astype(np.float32)
     gray = np.where(d16 == 0, np.float32(-2.0), gray).astype(np.float32)
     return gray, depth, sigma
+
+
+def write_keyframe_store(path, K, width, height, keyframes, latest_id, levels=3, culls=2):
+    """The binary keyframe store of dvo_vo_save / dvo_vo_load (csrc/dvo_store.cpp) written from oracle frames (orc.OFrame):
+    lets a test put the ORACLE's FrameHistory into a dvo_vo handle, so that one odometrize() call can be compared given
+    identical inputs (the free-running pipelines drift apart: DESIGN.md §6, sensitivity of the mapping to 1e-8 pose differences)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"DVOKF01\0")
+        f.write(struct.pack("<8i", 1, width, height, levels, culls, len(keyframes), latest_id, 0))
+        f.write(np.asarray(K, np.float32).reshape(9).tobytes())
+        for kf in keyframes:
+            f.write(struct.pack("<2i", int(kf.c.id), int(kf.c.ref_index)))
+            f.write(np.asarray(kf.xi, np.float32).tobytes())
+            f.write(np.asarray(kf.rel_xi, np.float32).tobytes())
+            for l in range(levels):
+                f.write(np.ascontiguousarray(kf.gray(l), np.float32).tobytes())
+            top = levels - 1
+            f.write(np.ascontiguousarray(kf.depth(top), np.float32).tobytes())
+            f.write(np.ascontiguousarray(kf.sigma(top), np.float32).tobytes())
+            f.write(np.ascontiguousarray(kf.age(), np.float32).tobytes())
