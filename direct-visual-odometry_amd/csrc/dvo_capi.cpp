@@ -3,13 +3,13 @@
 
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "dvo_engine.h"
 
 using namespace dvo;
 
 struct dvo_vo { VisualOdometry impl; };
-struct dvo_batch { Batch impl; };
 
 extern "C" {
 
@@ -193,27 +193,41 @@ int dvo_batch_create(int n_seq, const float K[9], int width, int height, int lev
 int dvo_batch_destroy(dvo_batch* b)
 {
     if (!b) return DVO_OK;
-    (void)select_device(b->impl.device);
-    if (b->impl.stream) (void)hipStreamSynchronize(b->impl.stream);
+    if (b->mono) {
+        (void)select_device(b->mono->device);
+        if (b->mono->stream) (void)hipStreamSynchronize(b->mono->stream);
+    } else {
+        (void)select_device(b->impl.device);
+        if (b->impl.stream) (void)hipStreamSynchronize(b->impl.stream);
+    }
     delete b;
     return DVO_OK;
 }
 
+// a mono batch (dvo_batch_create_mono) has no sensor-depth entry points
+#define DVO_NOT_MONO(b)                                                                                   \
+    do {                                                                                                  \
+        if ((b)->mono) { set_error("this entry point needs a sensor-depth batch (dvo_batch_create)"); return DVO_ERR_BAD_ARGUMENT; } \
+    } while (0)
+
 int dvo_batch_push_device(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     return b->impl.push_device(gray, depth, sigma);
 }
 
 int dvo_batch_prefetch_device(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     return b->impl.prefetch_device(gray, depth, sigma);
 }
 
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
 {
     if (!b || !gray || !depth || !sigma) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     Batch& B = b->impl;
     DVO_TRY(select_device(B.device));
     const size_t n = (size_t)B.n_seq * B.g.src_w * B.g.src_h * sizeof(float);
@@ -227,6 +241,7 @@ int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, con
 int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     Batch& B = b->impl;
     if (!B.have_poses) return DVO_ERR_NOT_READY;
     DVO_TRY(select_device(B.device));
@@ -239,6 +254,7 @@ int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel)
 int dvo_batch_copy_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     Batch& B = b->impl;
     if (!B.have_poses) return DVO_ERR_NOT_READY;
     DVO_TRY(select_device(B.device));
@@ -249,7 +265,17 @@ int dvo_batch_copy_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_de
 
 int dvo_batch_last_track_log(dvo_batch* b, int seq, dvo_track_log* log)
 {
-    if (!b || !log || seq < 0 || seq >= b->impl.n_seq) return DVO_ERR_BAD_ARGUMENT;
+    if (!b || !log || seq < 0) return DVO_ERR_BAD_ARGUMENT;
+    if (b->mono) {  // the log of the last tracked frame of a mono batch
+        MonoBatch& M = *b->mono;
+        if (seq >= M.n_seq) return DVO_ERR_BAD_ARGUMENT;
+        if (M.latest_id < 1) return DVO_ERR_NOT_READY;
+        DVO_TRY(select_device(M.device));
+        DVO_HIP(hipMemcpyAsync(log, M.trk.log.as<dvo_track_log>() + seq, sizeof *log, hipMemcpyDeviceToHost, M.stream));
+        DVO_HIP(hipStreamSynchronize(M.stream));
+        return DVO_OK;
+    }
+    if (seq >= b->impl.n_seq) return DVO_ERR_BAD_ARGUMENT;
     Batch& B = b->impl;
     if (!B.have_poses) return DVO_ERR_NOT_READY;
     DVO_TRY(select_device(B.device));
@@ -261,6 +287,11 @@ int dvo_batch_last_track_log(dvo_batch* b, int seq, dvo_track_log* log)
 int dvo_batch_synchronize(dvo_batch* b)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
+    if (b->mono) {
+        DVO_TRY(select_device(b->mono->device));
+        DVO_HIP(hipStreamSynchronize(b->mono->stream));
+        return DVO_OK;
+    }
     DVO_TRY(select_device(b->impl.device));
     DVO_HIP(hipStreamSynchronize(b->impl.stream));
     return DVO_OK;
@@ -269,18 +300,19 @@ int dvo_batch_synchronize(dvo_batch* b)
 int dvo_batch_profile(dvo_batch* b, dvo_gn_profile* out, int reset)
 {
     if (!b || !out) return DVO_ERR_BAD_ARGUMENT;
-    Batch& B = b->impl;
-    DVO_TRY(select_device(B.device));
-    DVO_TRY(B.trk.collect_profile(B.stream));
+    Tracker& trk = b->mono ? b->mono->trk : b->impl.trk;
+    hipStream_t st = b->mono ? b->mono->stream : b->impl.stream;
+    DVO_TRY(select_device(b->mono ? b->mono->device : b->impl.device));
+    DVO_TRY(trk.collect_profile(st));
     unsigned long long c[2] = {0, 0};
-    DVO_HIP(hipMemcpy(c, B.trk.counters.p, sizeof c, hipMemcpyDeviceToHost));
-    out->gn_ms = B.trk.prof_ms;
-    out->gn_launches = B.trk.prof_launches;
+    DVO_HIP(hipMemcpy(c, trk.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    out->gn_ms = trk.prof_ms;
+    out->gn_launches = trk.prof_launches;
     out->gn_pixels = c[0];
     out->gn_iterations = c[1];
     if (reset) {
-        B.trk.prof_ms = 0; B.trk.prof_launches = 0;
-        DVO_HIP(hipMemset(B.trk.counters.p, 0, sizeof c));
+        trk.prof_ms = 0; trk.prof_launches = 0;
+        DVO_HIP(hipMemset(trk.counters.p, 0, sizeof c));
     }
     return DVO_OK;
 }
@@ -288,6 +320,7 @@ int dvo_batch_profile(dvo_batch* b, dvo_gn_profile* out, int reset)
 int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, uint64_t* pixels_per_launch)
 {
     if (!b || !avg_ms || n_launches < 1) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
     Batch& B = b->impl;
     if (level < 0 || level >= B.g.levels) return DVO_ERR_BAD_ARGUMENT;
     if (B.cur < 0 || !B.have_poses) return DVO_ERR_NOT_READY;
@@ -574,6 +607,7 @@ int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float*
     const size_t n = (size_t)w * h;
     std::vector<DevBuf> grays(n_hist);
     std::vector<AgeEntry> tab(n_hist);
+    std::vector<const float*> gptr(n_hist);
     for (int i = 0; i < n_hist; i++) {
         DVO_TRY(upload(grays[i], hist_gray[i], n, c.s));
         float nb[6], r_xi[6];
@@ -581,20 +615,26 @@ int dvo_op_depth_update(int dev, const dvo_config* cfg, int n_hist, const float*
         se3_concatenate_f(obj_xi, nb, r_xi);
         pose_from_xi(r_xi, -1.0f, tab[i].pose);
         for (int k = 0; k < 3; k++) tab[i].tneg[k] = -r_xi[k];
-        tab[i].gray = grays[i].as<float>();
+        tab[i].slot = i;
+        gptr[i] = grays[i].as<float>();
     }
-    DevBuf og, rd, rs, ra, ages, vd;
+    DevBuf og, rd, rs, ra, ages, vd, gtab;
     DVO_TRY(upload(og, obj_gray, n, c.s));
     DVO_TRY(upload(rd, ref_depth, n, c.s));
     DVO_TRY(upload(rs, ref_sigma, n, c.s));
     DVO_TRY(upload(ra, ref_age, n, c.s));
     DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist));
     DVO_HIP(hipMemcpyAsync(ages.p, tab.data(), sizeof(AgeEntry) * (size_t)n_hist, hipMemcpyHostToDevice, c.s));
+    DVO_TRY(gtab.alloc(sizeof(float*) * (size_t)n_hist));
+    DVO_HIP(hipMemcpyAsync(gtab.p, gptr.data(), sizeof(float*) * (size_t)n_hist, hipMemcpyHostToDevice, c.s));
     DVO_TRY(vd.alloc(sizeof(int)));
     DVO_HIP(hipMemsetAsync(vd.p, 0, sizeof(int), c.s));
     UpdateArgs a;
+    memset(&a, 0, sizeof a);
     a.ref_depth = rd.as<float>(); a.ref_sigma = rs.as<float>(); a.ref_age = ra.as<float>();
     a.obj_gray = og.as<float>(); a.ages = ages.as<AgeEntry>();
+    a.ring_gray = nullptr; a.gray_table = gtab.as<const float*>(); a.meta = nullptr;
+    a.n_seq = 1; a.R = n_hist;
     a.n_hist = n_hist; a.w = w; a.h = h; a.crop = cf.crop_enable; a.obj_id = obj_id; a.seed = cf.rng_seed;
     a.clamp_age = 0;
     a.k = intr_of(K);

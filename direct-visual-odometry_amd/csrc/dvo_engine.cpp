@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -503,11 +504,14 @@ int VisualOdometry::init(const float K9[9], int width, int height, const dvo_con
     DVO_TRY(tmp_a.alloc(tn * 4)); DVO_TRY(tmp_b.alloc(tn * 4)); DVO_TRY(tmp_c.alloc(tn * 4));
     DVO_TRY(owner.alloc(tn * 4));
     DVO_TRY(valid_dev.alloc(sizeof(int)));
+    DVO_TRY(meta_dev.alloc(sizeof(MonoSeq)));
+    DVO_HIP(hipMemset(meta_dev.p, 0, sizeof(MonoSeq)));
+    memset(&h_meta, 0, sizeof h_meta);
     memset(&last_log, 0, sizeof last_log);
     return DVO_OK;
 }
 
-static void default_initial_depth(int n, uint32_t seed, std::vector<float>& d, std::vector<float>& s)
+void default_initial_depth(int n, uint32_t seed, std::vector<float>& d, std::vector<float>& s)
 {  // stands in for cv::randn(depth, 1.5, 0.5); max(depth, 0.5); sigma = 0.5 (frame.hpp:17-21), deviation D6
     d.resize(n); s.assign(n, 0.5f);
     for (int i = 0; i < n; i++) {
@@ -538,12 +542,16 @@ int VisualOdometry::init_keyframe(const float* gray, const float* depth, const f
 }
 
 int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
-{  // Mapper::propagate, mapper.cpp:62-74
+{  // Mapper::propagate, mapper.cpp:62-74; the pose exp(+rel_xi) is the one k_mono_decide left in meta_dev
     const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
-    Pose pose;
-    pose_from_xi(frame.rel_xi, 1.0f, pose);
-    launch_propagate(ref.fs.depth[T], ref.fs.sigma[T], ref.age.as<float>(), tw, th, geoM.k[T], pose, frame.rel_xi[2],
-                     owner.as<int>(), frame.fs.depth[T], frame.fs.sigma[T], frame.age.as<float>(), stream);
+    PropArgs a;
+    a.ref_depth = ref.fs.depth[T]; a.ref_sigma = ref.fs.sigma[T]; a.ref_age = ref.age.as<float>();
+    a.depth = frame.fs.depth[T]; a.sigma = frame.fs.sigma[T]; a.age = frame.age.as<float>();
+    a.owner = owner.as<int>();
+    a.w = tw; a.h = th; a.n_seq = 1; a.k = geoM.k[T];
+    a.meta = meta_dev.as<MonoSeq>();
+    memset(&a.pose, 0, sizeof a.pose); a.tz = 0.0f;
+    launch_propagate_batch(a, stream);
     redecimate(frame.fs, frame.fs.depth[T], frame.fs.sigma[T], stream);  // Frame::updateDepthSigmaAge, frame.cpp:47-54
     return DVO_OK;
 }
@@ -553,33 +561,42 @@ int VisualOdometry::map_update(Keyframe& obj)
     Keyframe& ref = *hist.back();
     const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
     const int n_hist = (int)hist.size();
-    std::vector<AgeEntry> tab(n_hist);
-    for (int i = 0; i < n_hist; i++) {  // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe
-        float nb[6], r_xi[6];
-        for (int k = 0; k < 6; k++) nb[k] = -hist[i]->xi[k];
-        se3_concatenate_f(obj.xi, nb, r_xi);
-        pose_from_xi(r_xi, -1.0f, tab[i].pose);
-        for (int k = 0; k < 3; k++) tab[i].tneg[k] = -r_xi[k];
-        tab[i].gray = hist[i]->fs.gray[T];
+    // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe, on the device (k_age_table)
+    std::vector<float> hx((size_t)n_hist * 6);
+    std::vector<const float*> gt((size_t)n_hist);
+    for (int i = 0; i < n_hist; i++) {
+        memcpy(&hx[(size_t)i * 6], hist[i]->xi, 6 * sizeof(float));
+        gt[i] = hist[i]->fs.gray[T];
     }
-    if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
-    DVO_HIP(hipMemcpyAsync(ages.p, tab.data(), sizeof(AgeEntry) * (size_t)n_hist, hipMemcpyHostToDevice, stream));
-    DVO_HIP(hipMemsetAsync(valid_dev.p, 0, sizeof(int), stream));
+    if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) {
+        DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
+        DVO_TRY(hist_xi_dev.alloc(sizeof(float) * 6 * (size_t)n_hist * 2));
+        DVO_TRY(gray_tab_dev.alloc(sizeof(float*) * (size_t)n_hist * 2));
+    }
+    DVO_HIP(hipMemcpyAsync(hist_xi_dev.p, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(gray_tab_dev.p, gt.data(), gt.size() * sizeof(float*), hipMemcpyHostToDevice, stream));
+    AgeTableArgs ta;
+    ta.meta = meta_dev.as<MonoSeq>(); ta.hist_xi = hist_xi_dev.as<float>(); ta.ages = ages.as<AgeEntry>();
+    ta.n_seq = 1; ta.R = n_hist; ta.n_hist = n_hist;
+    launch_age_table(ta, stream);
     UpdateArgs a;
+    memset(&a, 0, sizeof a);
     a.ref_depth = ref.fs.depth[T]; a.ref_sigma = ref.fs.sigma[T]; a.ref_age = ref.age.as<float>();
     a.obj_gray = obj.fs.gray[T];
     a.ages = ages.as<AgeEntry>();
-    a.n_hist = n_hist; a.w = tw; a.h = th; a.crop = cfg.crop_enable; a.obj_id = obj.id;
+    a.ring_gray = nullptr;
+    a.gray_table = gray_tab_dev.as<const float*>();
+    a.meta = meta_dev.as<MonoSeq>();
+    a.n_seq = 1; a.R = n_hist; a.n_hist = n_hist; a.w = tw; a.h = th; a.crop = cfg.crop_enable; a.obj_id = obj.id;
     a.clamp_age = history_limit > 0 ? 1 : 0;
     a.seed = cfg.rng_seed;
     a.k = geoM.k[T];
     memcpy(a.K9, geoM.K9[T], sizeof a.K9);
-    pose_from_xi(obj.rel_xi, 1.0f, a.rel_pose);
-    a.rel_tz = obj.rel_xi[2];
-    a.valid_updates = valid_dev.as<int>();
+    a.valid_updates = nullptr;
     launch_depth_update(a, stream);
-    DVO_HIP(hipMemcpyAsync(&last_valid_updates, valid_dev.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipStreamSynchronize(stream));  // `tab` is pageable host memory: keep it alive until the copy is done
+    DVO_HIP(hipMemcpyAsync(&last_valid_updates, reinterpret_cast<char*>(meta_dev.p) + offsetof(MonoSeq, valid_updates), sizeof(int),
+                           hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));  // hx / gt are pageable host memory: keep them alive until the copies are done
     redecimate(ref.fs, ref.fs.depth[T], ref.fs.sigma[T], stream);  // mapper.cpp:135
     return DVO_OK;
 }
@@ -622,20 +639,26 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     }
     Keyframe& ref = *hist.back();
     DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
-    float rel[6];
-    DVO_HIP(hipMemcpyAsync(rel, trkM.xi_out.p, sizeof rel, hipMemcpyDeviceToHost, stream));
+    // Frame::updateXi (frame.cpp:7-14), Mapper::needNewFrame (mapper.cpp:45-60) and exp(xi) (system.hpp:73) on the device, by the
+    // kernel the batched pipeline uses; the host keeps FrameHistory, so the reference keyframe's pose and id go up first.
+    struct { float ref_xi[6]; int ref_id; int n_total; } hdr;
+    memcpy(hdr.ref_xi, ref.xi, sizeof hdr.ref_xi);
+    hdr.ref_id = ref.id; hdr.n_total = (int)hist.size();
+    static_assert(offsetof(MonoSeq, frame_xi) == 32, "MonoSeq starts with ref_xi, ref_id, n_total");
+    DVO_HIP(hipMemcpyAsync(meta_dev.p, &hdr, sizeof hdr, hipMemcpyHostToDevice, stream));
+    launch_mono_decide(meta_dev.as<MonoSeq>(), trkM.state.as<SeqState>(), 1, frame.id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
+                       nullptr, nullptr, nullptr, stream);
+    DVO_HIP(hipMemcpyAsync(&h_meta, meta_dev.p, sizeof h_meta, hipMemcpyDeviceToHost, stream));
     DVO_HIP(hipMemcpyAsync(&last_log, trkM.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
     DVO_HIP(hipStreamSynchronize(stream));
-    memcpy(frame.rel_xi, rel, sizeof rel);  // Frame::updateXi, frame.cpp:7-14
+    memcpy(frame.rel_xi, h_meta.rel_xi, sizeof frame.rel_xi);
+    memcpy(frame.xi, h_meta.frame_xi, sizeof frame.xi);
     frame.ref_id = ref.id;
-    se3_concatenate_f(ref.xi, rel, frame.xi);
-    // Mapper::estimate, mapper.cpp:16-33
-    const double tn2 = (double)rel[0] * rel[0] + (double)rel[1] * rel[1] + (double)rel[2] * rel[2];
-    const bool need = std::sqrt(tn2) > (double)cfg.keyframe_min_translation || (frame.id - ref.id >= cfg.keyframe_max_frames);  // mapper.cpp:45-60
+    const bool need = h_meta.need != 0;
     memcpy(last_xi, frame.xi, sizeof last_xi);
     memcpy(last_rel, frame.rel_xi, sizeof last_rel);
     last_id = frame.id;
-    se3_exp_f(frame.xi, T_world);  // system.hpp:73
+    memcpy(T_world, h_meta.T_world, 16 * sizeof(float));
     if (need) {
         DVO_TRY(map_propagate(frame, ref));
         hist.push_back(std::move(scratch));

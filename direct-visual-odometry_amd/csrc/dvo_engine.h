@@ -141,6 +141,10 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     std::unique_ptr<Keyframe> depth_ref, depth_cur;    // m_ref_frame of odometrizeUsingDepth
     DevBuf in_gray, in_depth, in_sigma;                // full-resolution staging
     DevBuf tmp_a, tmp_b, tmp_c, owner, ages, valid_dev;
+    // Mapper state of this sequence on the device (the same kernels as the batched mono pipeline: k_mono_decide, k_age_table),
+    // so that a dvo_vo handle and a sequence of a mono dvo_batch produce identical bits.
+    DevBuf meta_dev, hist_xi_dev, gray_tab_dev;
+    MonoSeq h_meta;
     std::vector<float> init_depth, init_sigma;
     int latest_id = -1;                                // Frame::latest_id, frame.cpp:5
     int history_limit = 0;                             // 0 = keep every keyframe (the reference); N = keep the newest N
@@ -197,4 +201,37 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
 
 int select_device(int device);
 
+// n_seq independent MONO sequences on one GPU: System::VisualOdometry::odometrize (system.hpp:44-74) -- track against the newest
+// keyframe, then Mapper::estimate (propagate + new keyframe, or stereo update) and regularize -- for every sequence per call, with
+// the keyframe decision taken on the device per sequence.  FrameHistory is a ring of the newest R keyframes per sequence
+// (their top-level gray + pose; the reference keeps every frame forever, frame.hpp:146-188): with R >= the number of keyframes
+// a run creates the results equal the reference's unbounded history, beyond that a dvo_vo handle with history limit R.
+struct MonoBatch {
+    int n_seq = 0, device = 0, R = 8;
+    dvo_config cfg;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Geometry g;              // Frame(gray, K, 3, 2), system.hpp:47
+    Tracker trk;
+    FrameSet ref, frm;       // newest keyframe of every sequence; the frame being processed
+    DevBuf ref_age, frm_age, owner, tmp, ring_gray, hist_xi, ages, meta, init_depth, init_sigma;
+    DevBuf xi_world, T_world, is_key;
+    int latest_id = -1;      // Frame::latest_id, frame.cpp:5 (all sequences advance in lockstep)
+    bool have_init = false;
+    int init(int n, const float K9[9], int w, int h, int ring, const dvo_config* c);
+    ~MonoBatch();
+    int set_initial_depth(const float* depth_host, const float* sigma_host);              // one map, broadcast to every sequence
+    int set_initial_depth_device(const float* depth_dev, const float* sigma_dev);         // [n_seq][th][tw]
+    int odometrize_device(const float* gray_dev);                                          // [n_seq][h][w]
+    int top_pixels() const { return g.w[g.top()] * g.h[g.top()]; }
+};
+
+void default_initial_depth(int n, uint32_t seed, std::vector<float>& d, std::vector<float>& s);
+
 }  // namespace dvo
+
+// the C handle behind dvo_batch*: a sensor-depth batch (impl) or, when `mono` is set, a mono track + map batch
+struct dvo_batch {
+    dvo::Batch impl;
+    std::unique_ptr<dvo::MonoBatch> mono;
+};

@@ -137,25 +137,88 @@ inline GnTiling gn_tiling(int w, int h, int ppt, int crop)
     return t;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mapping (src/map/mapper.cpp, src/map/implement.cpp) for n_seq sequences at once.  Every map is [n_seq][h][w] (top pyramid level);
+// a launch covers all sequences and each sequence takes part or not according to its own Mapper::needNewFrame flag, which
+// lives on the device (MonoSeq::need): no host round trip between tracking and mapping.
+// ------------------------------------------------------------------------------------------------
+struct MonoSeq {          // Mapper + FrameHistory state of one sequence (mapper.cpp:16-60, frame.hpp:146-188)
+    float ref_xi[6];      // Frame::m_xi of the newest keyframe           } the first 32 bytes are what a single dvo_vo handle
+    int   ref_id;         // its Frame::id                                } uploads before k_mono_decide (its FrameHistory
+    int   n_total;        // keyframes created so far                     } lives on the host)
+    float frame_xi[6];    // m_xi of the frame being processed = concatenate(ref_xi, rel_xi), frame.cpp:7-14
+    float rel_xi[6];      // m_relative_xi = Tracker::track's result
+    Pose  rel_pose;       // exp(+rel_xi): the warp of Mapper::propagate (mapper.cpp:66) and Mapper::update (mapper.cpp:94)
+    float T_world[16];    // exp(frame_xi), system.hpp:73
+    int   frame_id;
+    int   need;           // Mapper::needNewFrame (mapper.cpp:45-60) of this frame
+    int   valid_updates;  // "valid update: N pixel", mapper.cpp:136
+    int   pad;
+};
+
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)
     Pose  pose;        // exp(-r_xi), r_xi = concatenate(obj.xi, -born.xi)
     float tneg[3];     // -r_xi[0:3] (twist part; implement.cpp:56)
-    const float* gray; // born keyframe's top-level gray
+    int   slot;        // where the born keyframe's top-level gray lives: ring slot (batch) or history index (single handle)
+};
+
+struct AgeTableArgs {  // k_age_table: AgeEntry of every retained keyframe, once per frame and sequence (never per pixel)
+    const MonoSeq* meta;
+    const float* hist_xi;    // [n_seq][R][6], indexed by slot
+    AgeEntry* ages;          // [n_seq][R], indexed by HISTORY index (0 = oldest retained keyframe)
+    int n_seq, R;
+    int n_hist;              // >= 0: explicit history length and slot = index (single handle); < 0: ring, length min(n_total, R)
 };
 
 struct UpdateArgs {
-    float* ref_depth; float* ref_sigma; float* ref_age;   // in place (top level of the reference keyframe)
-    const float* obj_gray;
-    const AgeEntry* ages;    // [n_hist], index = history index (oldest first)
-    int n_hist, w, h, crop, obj_id;
+    float* ref_depth; float* ref_sigma; float* ref_age;   // [n_seq][h][w], in place (top level of the reference keyframes)
+    const float* obj_gray;                                 // [n_seq][h][w]
+    const AgeEntry* ages;            // [n_seq][R], index = history index (oldest first)
+    const float* ring_gray;          // [n_seq][R][h][w]: top-level gray of the retained keyframes (batch), or nullptr
+    const float* const* gray_table;  // [n_hist] device pointers (single handle / operator level), used when ring_gray == nullptr
+    const MonoSeq* meta;             // rel_pose, rel_xi[2], n_total, need, valid_updates per sequence; nullptr: the explicit fields
+    int n_seq, R, n_hist, w, h, crop, obj_id;
     int clamp_age;           // bounded history: a pixel born in a dropped keyframe searches the oldest retained one
     uint32_t seed;
     Intr k;
     float K9[9];
-    Pose rel_pose;           // exp(+rel_xi)
-    float rel_tz;            // rel_xi[2]
-    int* valid_updates;
+    Pose rel_pose;           // exp(+rel_xi)          } operator level only (meta == nullptr)
+    float rel_tz;            // rel_xi[2]             }
+    int* valid_updates;      //                       }
 };
+
+struct PropArgs {      // Implement::propagate (implement.cpp:217-256)
+    const float* ref_depth; const float* ref_sigma; const float* ref_age;   // [n_seq][h][w]
+    float* depth; float* sigma; float* age;                                  // [n_seq][h][w]
+    int* owner;                                                              // [n_seq][h][w] scratch
+    int w, h, n_seq;
+    Intr k;
+    const MonoSeq* meta;     // per-sequence pose + need flag; nullptr: `pose` / `tz` below, unconditional
+    Pose pose; float tz;
+};
+
+#define DVO_PROMOTE_MAX_SEG 8
+struct PromoteArgs {   // a tracked frame becomes the newest keyframe of the sequences whose need flag is set (mapper.cpp:23-27)
+    const float* src[DVO_PROMOTE_MAX_SEG];   // [n_seq][count] blocks of the frame set ...
+    float* dst[DVO_PROMOTE_MAX_SEG];         // ... copied over the same blocks of the reference set
+    int count[DVO_PROMOTE_MAX_SEG];
+    int n_seg, n_seq;
+    const float* gray_top;   // [n_seq][npix] also pushed into the keyframe ring:
+    float* ring_gray;        // [n_seq][R][npix], slot n_total % R
+    int npix, R;
+    const MonoSeq* meta;
+    int all;                 // 1: every sequence (first frame), 0: need flag
+};
+
+void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
+                        float* xi_world, float* T_world, int* is_key, hipStream_t s);
+void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,
+                        hipStream_t s);
+void launch_age_table(const AgeTableArgs& a, hipStream_t s);
+void launch_promote(const PromoteArgs& a, hipStream_t s);
+void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s);  // dst[seq][i] = src[i]
+void launch_propagate_batch(const PropArgs& a, hipStream_t s);
+void launch_regularize_batch(const float* depth, const float* sigma, int w, int h, int n_seq, float* out, hipStream_t s);
 
 void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s);
 void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s);

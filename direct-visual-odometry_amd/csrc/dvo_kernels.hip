@@ -955,178 +955,7 @@ __global__ void k_se3(int op, const float* in_a, const float* in_b, float* out)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Mapping kernels (src/map/implement.cpp)
-// ------------------------------------------------------------------------------------------------
-// Implement::propagate (implement.cpp:217-256).  The reference's forEach scatter races; its sequential
-// semantics are "last writer in raster order wins" (D7).  Three passes reproduce that exactly:
-//   pass 0: outputs <- (1, 1, 0), owner <- -1;  pass 1: owner[target] = max(source index);
-//   pass 2: every target pulls depth/sigma/age from its owning source pixel.
-__global__ void __launch_bounds__(256) k_propagate_init(float* depth, float* sigma, float* age, int* owner, int n)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    depth[i] = 1.0f; sigma[i] = 1.0f; age[i] = 0.0f; owner[i] = -1;
-}
-
-__global__ void __launch_bounds__(256) k_propagate_owner(const float* __restrict__ ref_depth, int w, int h, Intr k, Pose pose, int* owner)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= w * h) return;
-    const int y = i / w, x = i - y * w;
-    const float rd = ref_depth[i];
-    if (is_epsilon(rd)) return;
-    float pu, pv;
-    warp(pose, k, (float)x, (float)y, rd, pu, pv);
-    int qx, qy;
-    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
-    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
-    atomicMax(&owner[qy * w + qx], i);
-}
-
-__global__ void __launch_bounds__(256) k_propagate_pull(const float* __restrict__ ref_depth, const float* __restrict__ ref_sigma,
-                                                        const float* __restrict__ ref_age, const int* __restrict__ owner, int n, float tz,
-                                                        float* depth, float* sigma, float* age)
-{
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= n) return;
-    const int i = owner[o];
-    if (i < 0) return;
-    const float rd = ref_depth[i];
-    float s = ref_sigma[i];
-    const float d0 = rd < 0.01f ? 0.01f : rd;
-    const float d1 = d0 + tz;
-    const float q = d1 / d0;
-    const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
-    s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
-    depth[o] = d1 < 0.0f ? 0.0f : d1;
-    sigma[o] = s;
-    age[o] = ref_age[i] + 1.0f;
-}
-
-// Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
-__global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ depth, const float* __restrict__ sigma, int w, int h, float* __restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= w * h) return;
-    const int y = i / w, x = i - y * w;
-    float gd = depth[i], gs = sigma[i];
-    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
-    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
-    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
-    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
-    out[i] = gd < 6.0f ? gd : 6.0f;
-}
-
-// Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per
-// reference pixel.  FP32-VALU / gather-latency bound (<= 102 search steps x 3 bilinear samples), not HBM
-// bound.  The per-age relative poses are precomputed on the host (never a per-pixel exp/log).
-__global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int w = a.w, h = a.h;
-    if (i >= w * h) return;
-    const int y = i / w, x = i - y * w;
-    if (a.crop && (x < 16 || x > 144 || y < 12 || y > 108)) return;  // mapper.cpp:90
-    const float d = a.ref_depth[i];
-    float pu, pv;
-    warp(a.rel_pose, a.k, (float)x, (float)y, d, pu, pv);             // mapper.cpp:94
-    int qx, qy;
-    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
-    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
-    const int age = (int)a.ref_age[i];                                 // mapper.cpp:99
-    int bi = a.n_hist - 1 - age;                                       // frame.hpp:176
-    if (bi < 0 && a.clamp_age) bi = 0;
-    if (bi < 0 || bi >= a.n_hist) return;
-    const AgeEntry& born = a.ages[bi];
-    const float depth = d - a.rel_tz;                                  // mapper.cpp:104
-    const float sigma = a.ref_sigma[i];
-    const GlobalImg bg{born.gray, w, h};
-    // EpipolarSegment, implement.cpp:23-47
-    const float dmin = (depth - sigma) < 0.10f ? 0.10f : (depth - sigma);
-    const float dmax = depth + sigma;
-    float sx, sy, ex, ey;
-    warp(born.pose, a.k, (float)qx, (float)qy, dmax, sx, sy);
-    warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
-    const float sex = sx - ex, sey = sy - ey;
-    const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
-    // doMatching, implement.cpp:106-152
-    const float og = a.obj_gray[qy * w + qx];
-    const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
-    float ptx = sx, pty = sy, bestx = sx, besty = sy, min_ssd = 6.0f;
-    int count = 0;
-    for (;;) {
-        const float ddx = ptx - sx, ddy = pty - sy;
-        if (!(sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy) < (double)length)) break;
-        float ssd = 0.0f;
-        ptx += dirx;
-        pty += diry;
-        for (int j = 0; j < 3; j++) {
-            const float kf = (float)(j - 1);
-            const float tx = ptx + dirx * kf, ty = pty + diry * kf;
-            const float sgv = get_subpixel_dense(bg, tx, ty);
-            if (is_invalid(sgv)) { ssd = 6.0f; break; }
-            const float diff = sgv - og;
-            const int aw = 3 - abs(j - 2);
-            ssd = (float)((double)ssd + 1.0 * aw / 3 * (double)(diff * diff));  // implement.cpp:134
-        }
-        if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
-        if (count++ > 100) break;
-    }
-    if ((double)min_ssd > 3 * 0.1) return;                             // implement.cpp:145
-    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return;  // implement.cpp:196-200
-    // depthEstimate, implement.cpp:49-71 (double from float inputs)
-    float nd;
-    {
-        float q0f, q1f, q2f;
-        back_project(a.k, (float)qx, (float)qy, 1.0f, q0f, q1f, q2f);
-        const double q0 = q0f, q1 = q1f, q2 = q2f;
-        const double t[3] = {(double)born.tneg[0], (double)born.tneg[1], (double)born.tneg[2]};
-        const double xi3[3] = {(double)bestx, (double)besty, 1.0};
-        double Rq[3], KRq[3], Kt[3];
-        for (int r = 0; r < 3; r++)
-            Rq[r] = (double)born.pose.R[3 * r] * q0 + (double)born.pose.R[3 * r + 1] * q1 + (double)born.pose.R[3 * r + 2] * q2;
-        for (int r = 0; r < 3; r++) {
-            KRq[r] = (double)a.K9[3 * r] * Rq[0] + (double)a.K9[3 * r + 1] * Rq[1] + (double)a.K9[3 * r + 2] * Rq[2];
-            Kt[r] = (double)a.K9[3 * r] * t[0] + (double)a.K9[3 * r + 1] * t[1] + (double)a.K9[3 * r + 2] * t[2];
-        }
-        double aa = 0.0, ab = 0.0;
-        for (int r = 0; r < 3; r++) {
-            const double va = Rq[2] * xi3[r] - KRq[r];
-            const double vb = t[2] * xi3[r] - Kt[r];
-            aa += va * va;
-            ab += va * vb;
-        }
-        nd = -(float)(ab / aa);
-    }
-    // sigmaEstimate, implement.cpp:73-104
-    float ns;
-    {
-        const float l = length;
-        const float lx = sex / l, ly = sey / l;
-        const float alpha = (dmax - dmin) / l;
-        int mx = 0, my = 0;
-        round_coord(bestx, mx);
-        round_coord(besty, my);
-        mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
-        my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
-        const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
-        if (is_invalid(gx) || is_invalid(gy)) return;  // new_sigma = -1 fails the gate of mapper.cpp:122
-        const float gl = fabsf(fmaf(gy, ly, gx * lx));
-        const float gl2 = gl * gl, gp2 = gl / l;
-        const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
-        const float lum = 0.5f / (gp2 < kEpsilon ? kEpsilon : gp2);
-        ns = alpha * sqrtf(epi + lum);
-    }
-    if (nd > 0.2f && nd < 6.0f && ns > 0.0f && ns < 0.5f) {            // mapper.cpp:122
-        float gd = depth, gs = sigma;
-        const float reset = rng_depth(a.seed, (uint32_t)a.obj_id, (uint32_t)i);
-        if (!gaussian_update(gd, gs, nd, ns, reset)) a.ref_age[i] = 0.0f;  // mapper.cpp:124-127
-        else atomicAdd(a.valid_updates, 1);
-        a.ref_depth[i] = gd;                                           // mapper.cpp:130-131
-        a.ref_sigma[i] = gs;
-    }
-}
+// (the mapping kernels -- propagate, regularize, depth update, keyframe promotion -- live in dvo_map_kernels.hip)
 
 // ------------------------------------------------------------------------------------------------
 // Dataset front-end kernels (what src/core/loader.cpp does on the CPU with OpenCV)
@@ -1394,25 +1223,6 @@ void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int
 void launch_se3(int op, const float* a, const float* b, float* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_se3, dim3(1), dim3(64), 0, s, op, a, b, out);
-}
-
-void launch_propagate(const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h, const Intr& k,
-                      const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s)
-{
-    const int n = w * h;
-    hipLaunchKernelGGL(k_propagate_init, dim3(cdiv(n, 256)), dim3(256), 0, s, depth, sigma, age, owner, n);
-    hipLaunchKernelGGL(k_propagate_owner, dim3(cdiv(n, 256)), dim3(256), 0, s, ref_depth, w, h, k, pose, owner);
-    hipLaunchKernelGGL(k_propagate_pull, dim3(cdiv(n, 256)), dim3(256), 0, s, ref_depth, ref_sigma, ref_age, owner, n, tz, depth, sigma, age);
-}
-
-void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_regularize, dim3(cdiv(w * h, 256)), dim3(256), 0, s, depth, sigma, w, h, out);
-}
-
-void launch_depth_update(const UpdateArgs& a, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_depth_update, dim3(cdiv(a.w * a.h, 256)), dim3(256), 0, s, a);
 }
 
 }  // namespace dvo

@@ -1,0 +1,418 @@
+// dvo_map_kernels.hip -- the mapping half of the hot path (src/map/mapper.cpp, src/map/implement.cpp) as gfx950 kernels, for
+// n_seq sequences per launch.  Maps are [n_seq][h][w] blocks of the top pyramid level; the workgroup index carries the sequence
+// (grid.x = workgroups per sequence * n_seq) and every kernel that belongs to one branch of Mapper::estimate (mapper.cpp:16-33)
+// starts by reading its sequence's need flag -- one scalar load -- and leaves if the sequence took the other branch.
+// The same kernels serve the single-sequence dvo_vo handle (n_seq = 1) and the operator-level entry points.
+// Built with -ffp-contract=off: only the fmaf() calls written here and in dvo_math.h fuse.
+#include <hip/hip_runtime.h>
+
+#include "dvo_kernels.h"
+
+namespace dvo {
+
+static inline unsigned cdiv_u(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// (sequence, pixel) of a thread; false when the thread has no pixel
+__device__ __forceinline__ bool seq_pixel(int npix, int& seq, int& i)
+{
+    const unsigned bps = ((unsigned)npix + 255u) >> 8;
+    seq = (int)(blockIdx.x / bps);
+    i = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + (int)threadIdx.x;
+    return i < npix;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mono_decide: what System::VisualOdometry::odometrize does between Tracker::track and Mapper::estimate
+// (system.hpp:57-73, frame.cpp:7-14, mapper.cpp:45-60), one thread per sequence, in the double-precision pose algebra of
+// dvo_math.h: rel_xi <- the tracker's twist, frame_xi <- concatenate(ref_xi, rel_xi), need <- needNewFrame,
+// rel_pose <- exp(+rel_xi), T_world <- exp(frame_xi).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation,
+                                                    int max_frames, float* xi_world, float* T_world, int* is_key)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_seq) return;
+    MonoSeq& m = meta[s];
+    float rel[6], ref[6], fx[6];
+    for (int i = 0; i < 6; i++) { rel[i] = state[s].xi[i]; ref[i] = m.ref_xi[i]; }
+    se3_concatenate_f(ref, rel, fx);
+    const double tn2 = (double)rel[0] * rel[0] + (double)rel[1] * rel[1] + (double)rel[2] * rel[2];
+    const int need = (sqrt(tn2) > (double)min_translation || (frame_id - m.ref_id >= max_frames)) ? 1 : 0;  // mapper.cpp:45-60
+    float T[16];
+    se3_exp_f(fx, T);
+    Pose rp;
+    pose_from_xi(rel, 1.0f, rp);
+    for (int i = 0; i < 6; i++) { m.rel_xi[i] = rel[i]; m.frame_xi[i] = fx[i]; }
+    m.rel_pose = rp;
+    for (int i = 0; i < 16; i++) m.T_world[i] = T[i];
+    m.frame_id = frame_id;
+    m.need = need;
+    m.valid_updates = 0;
+    if (xi_world) for (int i = 0; i < 6; i++) xi_world[s * 6 + i] = fx[i];
+    if (T_world) for (int i = 0; i < 16; i++) T_world[s * 16 + i] = T[i];
+    if (is_key) is_key[s] = need;
+}
+
+// k_mono_commit: FrameHistory::setRefFrame / push (frame.hpp:151-157) for the sequences that created a keyframe: the frame's
+// pose becomes the reference pose and enters the ring.  all = 1: first frame (identity pose, every sequence).
+__global__ void __launch_bounds__(64) k_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world,
+                                                    float* T_world, int* is_key)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_seq) return;
+    MonoSeq& m = meta[s];
+    if (all) {
+        for (int i = 0; i < 6; i++) { m.ref_xi[i] = 0.0f; m.frame_xi[i] = 0.0f; m.rel_xi[i] = 0.0f; }
+        for (int i = 0; i < 9; i++) m.rel_pose.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        for (int i = 0; i < 3; i++) m.rel_pose.t[i] = 0.0f;
+        for (int i = 0; i < 16; i++) m.T_world[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        m.ref_id = frame_id; m.frame_id = frame_id; m.n_total = 1; m.need = 1; m.valid_updates = 0;
+        for (int i = 0; i < 6; i++) hist_xi[((size_t)s * R) * 6 + i] = 0.0f;
+        if (xi_world) for (int i = 0; i < 6; i++) xi_world[s * 6 + i] = 0.0f;
+        if (T_world) for (int i = 0; i < 16; i++) T_world[s * 16 + i] = m.T_world[i];
+        if (is_key) is_key[s] = 1;
+        return;
+    }
+    if (!m.need) return;
+    const int slot = m.n_total % R;
+    for (int i = 0; i < 6; i++) { m.ref_xi[i] = m.frame_xi[i]; hist_xi[((size_t)s * R + slot) * 6 + i] = m.frame_xi[i]; }
+    m.ref_id = m.frame_id;
+    m.n_total += 1;
+}
+
+// k_age_table: the per-keyframe part of Mapper::update (mapper.cpp:99-107) hoisted out of the pixel loop: for every retained
+// keyframe, r_xi = concatenate(obj.xi, -born.xi), the pose exp(-r_xi) that the epipolar search warps with and -r_xi's
+// translation (implement.cpp:56).  One thread per (sequence, history index).
+__global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.n_seq * a.R) return;
+    const int seq = t / a.R, i = t - seq * a.R;
+    const MonoSeq& m = a.meta[seq];
+    int n_hist, slot;
+    if (a.n_hist >= 0) {          // single handle: the table is the whole FrameHistory, slot = history index
+        n_hist = a.n_hist; slot = i;
+    } else {                      // ring: the newest min(n_total, R) keyframes
+        if (m.need) return;       // (sequences that create a keyframe do not search)
+        n_hist = m.n_total < a.R ? m.n_total : a.R;
+        slot = (m.n_total - n_hist + i) % a.R;
+    }
+    if (i >= n_hist) return;
+    float ox[6], nb[6], r_xi[6];
+    for (int k = 0; k < 6; k++) { ox[k] = m.frame_xi[k]; nb[k] = -a.hist_xi[((size_t)seq * a.R + slot) * 6 + k]; }
+    se3_concatenate_f(ox, nb, r_xi);
+    AgeEntry e;
+    pose_from_xi(r_xi, -1.0f, e.pose);
+    for (int k = 0; k < 3; k++) e.tneg[k] = -r_xi[k];
+    e.slot = slot;
+    a.ages[(size_t)seq * a.R + i] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Implement::propagate (implement.cpp:217-256).  The reference's forEach scatter races; its sequential semantics are "last
+// writer in raster order wins" (D7).  Three passes reproduce that exactly:
+//   pass 0: outputs <- (1, 1, 0), owner <- -1;  pass 1: owner[target] = max(source index);
+//   pass 2: every target pulls depth/sigma/age from its owning source pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_propagate_init(PropArgs a)
+{
+    int seq, i;
+    const int n = a.w * a.h;
+    if (!seq_pixel(n, seq, i)) return;
+    if (a.meta && !a.meta[seq].need) return;
+    const size_t o = (size_t)seq * n + i;
+    a.depth[o] = 1.0f; a.sigma[o] = 1.0f; a.age[o] = 0.0f; a.owner[o] = -1;
+}
+
+__global__ void __launch_bounds__(256) k_propagate_owner(PropArgs a)
+{
+    int seq, i;
+    const int w = a.w, h = a.h, n = w * h;
+    if (!seq_pixel(n, seq, i)) return;
+    if (a.meta && !a.meta[seq].need) return;
+    const Pose pose = a.meta ? a.meta[seq].rel_pose : a.pose;   // wave-uniform
+    const int y = i / w, x = i - y * w;
+    const float rd = a.ref_depth[(size_t)seq * n + i];
+    if (is_epsilon(rd)) return;
+    float pu, pv;
+    warp(pose, a.k, (float)x, (float)y, rd, pu, pv);
+    int qx, qy;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
+    atomicMax(&a.owner[(size_t)seq * n + qy * w + qx], i);
+}
+
+__global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
+{
+    int seq, o;
+    const int n = a.w * a.h;
+    if (!seq_pixel(n, seq, o)) return;
+    if (a.meta && !a.meta[seq].need) return;
+    const float tz = a.meta ? a.meta[seq].rel_xi[2] : a.tz;
+    const size_t base = (size_t)seq * n;
+    const int i = a.owner[base + o];
+    if (i < 0) return;
+    const float rd = a.ref_depth[base + i];
+    float s = a.ref_sigma[base + i];
+    const float d0 = rd < 0.01f ? 0.01f : rd;
+    const float d1 = d0 + tz;
+    const float q = d1 / d0;
+    const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
+    s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
+    a.depth[base + o] = d1 < 0.0f ? 0.0f : d1;
+    a.sigma[base + o] = s;
+    a.age[base + o] = a.ref_age[base + i] + 1.0f;
+}
+
+// Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
+__global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ depth_all, const float* __restrict__ sigma_all, int w, int h,
+                                                    float* __restrict__ out_all)
+{
+    int seq, i;
+    if (!seq_pixel(w * h, seq, i)) return;
+    const size_t base = (size_t)seq * w * h;
+    const float* __restrict__ depth = depth_all + base;
+    const float* __restrict__ sigma = sigma_all + base;
+    const int y = i / w, x = i - y * w;
+    float gd = depth[i], gs = sigma[i];
+    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
+    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
+    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
+    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
+    out_all[base + i] = gd < 6.0f ? gd : 6.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per reference pixel of the
+// window mapper.cpp:90 keeps.  FP32-VALU / gather-latency bound (<= 102 search steps x 3 bilinear samples), not HBM bound.
+// The per-keyframe relative poses come from k_age_table (never a per-pixel exp/log).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
+{
+    const int w = a.w, h = a.h, npix = w * h;
+    // Only the window of mapper.cpp:90 (x in [16,144], y in [12,108]) is launched when the crop is on.
+    const int x_lo = a.crop ? 16 : 0, y_lo = a.crop ? 12 : 0;
+    const int ww = a.crop ? (min(144, w - 1) - 16 + 1) : w, wh = a.crop ? (min(108, h - 1) - 12 + 1) : h;
+    if (ww <= 0 || wh <= 0) return;
+    int seq, j;
+    if (!seq_pixel(ww * wh, seq, j)) return;
+    const MonoSeq* m = a.meta ? a.meta + seq : nullptr;
+    if (m && a.ring_gray && m->need) return;          // this sequence created a keyframe instead (mapper.cpp:23-27)
+    const int wy = j / ww, wx = j - wy * ww;
+    const int x = x_lo + wx, y = y_lo + wy, i = y * w + x;
+    const size_t base = (size_t)seq * npix;
+    const Pose rel_pose = m ? m->rel_pose : a.rel_pose;
+    const float rel_tz = m ? m->rel_xi[2] : a.rel_tz;
+    int n_hist = a.n_hist;
+    if (m && a.ring_gray) n_hist = m->n_total < a.R ? m->n_total : a.R;
+    const int obj_id = m ? m->frame_id : a.obj_id;
+    const float d = a.ref_depth[base + i];
+    float pu, pv;
+    warp(rel_pose, a.k, (float)x, (float)y, d, pu, pv);               // mapper.cpp:94
+    int qx, qy;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
+    const int age = (int)a.ref_age[base + i];                          // mapper.cpp:99
+    int bi = n_hist - 1 - age;                                         // frame.hpp:176
+    if (bi < 0 && a.clamp_age) bi = 0;
+    if (bi < 0 || bi >= n_hist) return;
+    const AgeEntry& born = a.ages[(size_t)seq * a.R + bi];
+    const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
+    const float depth = d - rel_tz;                                    // mapper.cpp:104
+    const float sigma = a.ref_sigma[base + i];
+    const GlobalImg bg{born_gray, w, h};
+    // EpipolarSegment, implement.cpp:23-47
+    const float dmin = (depth - sigma) < 0.10f ? 0.10f : (depth - sigma);
+    const float dmax = depth + sigma;
+    float sx, sy, ex, ey;
+    warp(born.pose, a.k, (float)qx, (float)qy, dmax, sx, sy);
+    warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
+    const float sex = sx - ex, sey = sy - ey;
+    const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
+    // doMatching, implement.cpp:106-152
+    const float og = a.obj_gray[base + qy * w + qx];
+    const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
+    float ptx = sx, pty = sy, bestx = sx, besty = sy, min_ssd = 6.0f;
+    int count = 0;
+    // The loop test of implement.cpp:113 is sqrt(dx^2 + dy^2) < length in double.  With L2 = length^2 (exact in double), that is
+    // decided without the square root whenever dx^2 + dy^2 is not within a relative 1e-12 of L2 (sqrt is monotonic and correctly
+    // rounded: its result can only differ from the exact root's side of `length` inside that band); inside the band the literal
+    // test runs.  Same decisions, one fp64 sqrt per pixel instead of one per step.
+    const double Ld = (double)length, L2 = Ld * Ld, L2lo = L2 * (1.0 - 1e-12), L2hi = L2 * (1.0 + 1e-12);
+    for (;;) {
+        const float ddx = ptx - sx, ddy = pty - sy;
+        const double q2 = (double)ddx * (double)ddx + (double)ddy * (double)ddy;
+        bool go;
+        if (q2 < L2lo) go = true;
+        else if (q2 > L2hi) go = false;
+        else go = sqrt(q2) < Ld;                  // (also the NaN case: every comparison above is false)
+        if (!go) break;
+        float ssd = 0.0f;
+        ptx += dirx;
+        pty += diry;
+        for (int jj = 0; jj < 3; jj++) {
+            const float kf = (float)(jj - 1);
+            const float tx = ptx + dirx * kf, ty = pty + diry * kf;
+            const float sgv = get_subpixel_dense(bg, tx, ty);
+            if (is_invalid(sgv)) { ssd = 6.0f; break; }
+            const float diff = sgv - og;
+            const int aw = 3 - abs(jj - 2);
+            ssd = (float)((double)ssd + 1.0 * aw / 3 * (double)(diff * diff));  // implement.cpp:134
+        }
+        if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
+        if (count++ > 100) break;
+    }
+    if ((double)min_ssd > 3 * 0.1) return;                             // implement.cpp:145
+    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return;  // implement.cpp:196-200
+    // depthEstimate, implement.cpp:49-71 (double from float inputs)
+    float nd;
+    {
+        float q0f, q1f, q2f;
+        back_project(a.k, (float)qx, (float)qy, 1.0f, q0f, q1f, q2f);
+        const double q0 = q0f, q1 = q1f, q2 = q2f;
+        const double t[3] = {(double)born.tneg[0], (double)born.tneg[1], (double)born.tneg[2]};
+        const double xi3[3] = {(double)bestx, (double)besty, 1.0};
+        double Rq[3], KRq[3], Kt[3];
+        for (int r = 0; r < 3; r++)
+            Rq[r] = (double)born.pose.R[3 * r] * q0 + (double)born.pose.R[3 * r + 1] * q1 + (double)born.pose.R[3 * r + 2] * q2;
+        for (int r = 0; r < 3; r++) {
+            KRq[r] = (double)a.K9[3 * r] * Rq[0] + (double)a.K9[3 * r + 1] * Rq[1] + (double)a.K9[3 * r + 2] * Rq[2];
+            Kt[r] = (double)a.K9[3 * r] * t[0] + (double)a.K9[3 * r + 1] * t[1] + (double)a.K9[3 * r + 2] * t[2];
+        }
+        double aa = 0.0, ab = 0.0;
+        for (int r = 0; r < 3; r++) {
+            const double va = Rq[2] * xi3[r] - KRq[r];
+            const double vb = t[2] * xi3[r] - Kt[r];
+            aa += va * va;
+            ab += va * vb;
+        }
+        nd = -(float)(ab / aa);
+    }
+    // sigmaEstimate, implement.cpp:73-104
+    float ns;
+    {
+        const float l = length;
+        const float lx = sex / l, ly = sey / l;
+        const float alpha = (dmax - dmin) / l;
+        int mx = 0, my = 0;
+        round_coord(bestx, mx);
+        round_coord(besty, my);
+        mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
+        my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
+        const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
+        if (is_invalid(gx) || is_invalid(gy)) return;  // new_sigma = -1 fails the gate of mapper.cpp:122
+        const float gl = fabsf(fmaf(gy, ly, gx * lx));
+        const float gl2 = gl * gl, gp2 = gl / l;
+        const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
+        const float lum = 0.5f / (gp2 < kEpsilon ? kEpsilon : gp2);
+        ns = alpha * sqrtf(epi + lum);
+    }
+    if (nd > 0.2f && nd < 6.0f && ns > 0.0f && ns < 0.5f) {            // mapper.cpp:122
+        float gd = depth, gs = sigma;
+        const float reset = rng_depth(a.seed, (uint32_t)obj_id, (uint32_t)i);
+        if (!gaussian_update(gd, gs, nd, ns, reset)) a.ref_age[base + i] = 0.0f;  // mapper.cpp:124-127
+        else atomicAdd(m ? const_cast<int*>(&m->valid_updates) : a.valid_updates, 1);
+        a.ref_depth[base + i] = gd;                                    // mapper.cpp:130-131
+        a.ref_sigma[base + i] = gs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_promote: the tracked frame becomes the newest keyframe (Mapper::estimate's needNewFrame branch, mapper.cpp:23-27 +
+// FrameHistory::push): its gray pyramid, the propagated top-level depth / sigma and the age map are copied over the reference
+// set's, and its top-level gray enters the keyframe ring (slot n_total % R).  One launch, every segment of every flagged sequence.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
+{
+    int total = a.npix;  // + the ring segment
+    for (int g = 0; g < a.n_seg; g++) total += a.count[g];
+    int seq, i;
+    if (!seq_pixel(total, seq, i)) return;
+    const MonoSeq& m = a.meta[seq];
+    if (!a.all && !m.need) return;
+    for (int g = 0; g < a.n_seg; g++) {
+        if (i < a.count[g]) {
+            const size_t o = (size_t)seq * a.count[g] + i;
+            a.dst[g][o] = a.src[g][o];
+            return;
+        }
+        i -= a.count[g];
+    }
+    const int slot = a.all ? 0 : m.n_total % a.R;   // (k_mono_commit increments n_total AFTER this kernel)
+    a.ring_gray[((size_t)seq * a.R + slot) * a.npix + i] = a.gray_top[(size_t)seq * a.npix + i];
+}
+
+__global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src, float* __restrict__ dst, int count)
+{
+    int seq, i;
+    if (!seq_pixel(count, seq, i)) return;
+    dst[(size_t)seq * count + i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrappers
+void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
+                        float* xi_world, float* T_world, int* is_key, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mono_decide, dim3(cdiv_u(n_seq, 64)), dim3(64), 0, s, meta, state, n_seq, frame_id, min_translation, max_frames,
+                       xi_world, T_world, is_key);
+}
+
+void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mono_commit, dim3(cdiv_u(n_seq, 64)), dim3(64), 0, s, meta, hist_xi, n_seq, R, all, frame_id, xi_world, T_world, is_key);
+}
+
+void launch_age_table(const AgeTableArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_age_table, dim3(cdiv_u((unsigned)a.n_seq * (unsigned)a.R, 64)), dim3(64), 0, s, a);
+}
+
+void launch_promote(const PromoteArgs& a, hipStream_t s)
+{
+    int total = a.npix;
+    for (int g = 0; g < a.n_seg; g++) total += a.count[g];
+    hipLaunchKernelGGL(k_promote, dim3(cdiv_u(total, 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+}
+
+void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_broadcast, dim3(cdiv_u(count, 256) * (unsigned)n_seq), dim3(256), 0, s, src, dst, count);
+}
+
+void launch_propagate_batch(const PropArgs& a, hipStream_t s)
+{
+    const dim3 grid(cdiv_u(a.w * a.h, 256) * (unsigned)a.n_seq);
+    hipLaunchKernelGGL(k_propagate_init, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_propagate_owner, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_propagate_pull, grid, dim3(256), 0, s, a);
+}
+
+void launch_propagate(const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h, const Intr& k,
+                      const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s)
+{
+    PropArgs a;
+    a.ref_depth = ref_depth; a.ref_sigma = ref_sigma; a.ref_age = ref_age;
+    a.depth = depth; a.sigma = sigma; a.age = age; a.owner = owner;
+    a.w = w; a.h = h; a.n_seq = 1; a.k = k; a.meta = nullptr; a.pose = pose; a.tz = tz;
+    launch_propagate_batch(a, s);
+}
+
+void launch_regularize_batch(const float* depth, const float* sigma, int w, int h, int n_seq, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_regularize, dim3(cdiv_u(w * h, 256) * (unsigned)n_seq), dim3(256), 0, s, depth, sigma, w, h, out);
+}
+
+void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s)
+{
+    launch_regularize_batch(depth, sigma, w, h, 1, out, s);
+}
+
+void launch_depth_update(const UpdateArgs& a, hipStream_t s)
+{
+    const int ww = a.crop ? ((a.w - 1 < 144 ? a.w - 1 : 144) - 16 + 1) : a.w, wh = a.crop ? ((a.h - 1 < 108 ? a.h - 1 : 108) - 12 + 1) : a.h;
+    if (ww <= 0 || wh <= 0) return;
+    hipLaunchKernelGGL(k_depth_update, dim3(cdiv_u(ww * wh, 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+}
+
+}  // namespace dvo

@@ -1,0 +1,246 @@
+// dvo_mono.cpp -- the batched MONO pipeline (BASELINE config "tracking + inverse-depth filter"): System::VisualOdometry::odometrize
+// (include/system/system.hpp:44-74) and Map::Mapper (src/map/mapper.cpp:16-144) for n_seq sequences per call.  One fixed launch
+// sequence per frame, no host round trip: every sequence's keyframe decision (Mapper::needNewFrame) is a flag in device memory that
+// the mapping kernels test per sequence.  Reference citations: file:line under the reference tree.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "dvo_engine.h"
+
+namespace dvo {
+
+MonoBatch::~MonoBatch()
+{
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+int MonoBatch::init(int n, const float K9[9], int w, int h, int ring, const dvo_config* c)
+{
+    if (n < 1 || !K9 || w < 64 || h < 64 || ring < 1 || ring > 64) { set_error("dvo_batch_create_mono: bad arguments"); return DVO_ERR_BAD_ARGUMENT; }
+    if (c) cfg = *c; else dvo_config_default(&cfg);
+    n_seq = n; R = ring; device = cfg.device;
+    DVO_TRY(select_device(device));
+    if (cfg.stream) stream = (hipStream_t)cfg.stream;
+    else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
+    DVO_TRY(make_geometry(K9, w, h, 3, 2, g));  // Frame(gray, K, 3, 2), system.hpp:47
+    DVO_TRY(ref.alloc(g, n, cfg));
+    DVO_TRY(frm.alloc(g, n, cfg));
+    DVO_TRY(trk.init(g, n, cfg));
+    const size_t np = (size_t)top_pixels(), all = np * (size_t)n * sizeof(float);
+    DVO_TRY(ref_age.alloc(all)); DVO_TRY(frm_age.alloc(all)); DVO_TRY(owner.alloc(all)); DVO_TRY(tmp.alloc(all));
+    DVO_TRY(ring_gray.alloc(all * (size_t)R));
+    DVO_TRY(hist_xi.alloc(sizeof(float) * 6 * (size_t)R * n));
+    DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)R * n));
+    DVO_TRY(meta.alloc(sizeof(MonoSeq) * (size_t)n));
+    DVO_TRY(init_depth.alloc(np * sizeof(float))); DVO_TRY(init_sigma.alloc(np * sizeof(float)));
+    DVO_TRY(xi_world.alloc(sizeof(float) * 6 * (size_t)n));
+    DVO_TRY(T_world.alloc(sizeof(float) * 16 * (size_t)n));
+    DVO_TRY(is_key.alloc(sizeof(int) * (size_t)n));
+    DVO_HIP(hipMemset(meta.p, 0, meta.bytes));
+    DVO_HIP(hipMemset(hist_xi.p, 0, hist_xi.bytes));
+    return DVO_OK;
+}
+
+int MonoBatch::set_initial_depth(const float* depth_host, const float* sigma_host)
+{  // replaces cv::randn(depth, 1.5, 0.5), max(depth, 0.5), sigma = 0.5 of the first mono keyframe (frame.hpp:17-21, D6)
+    if (!depth_host || !sigma_host) { set_error("null map"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const size_t np = (size_t)top_pixels();
+    DVO_HIP(hipMemcpy(init_depth.p, depth_host, np * sizeof(float), hipMemcpyHostToDevice));
+    DVO_HIP(hipMemcpy(init_sigma.p, sigma_host, np * sizeof(float), hipMemcpyHostToDevice));
+    const int T = g.top();
+    launch_broadcast(init_depth.as<float>(), ref.depth[T], (int)np, n_seq, stream);
+    launch_broadcast(init_sigma.as<float>(), ref.sigma[T], (int)np, n_seq, stream);
+    have_init = true;
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int MonoBatch::set_initial_depth_device(const float* depth_dev, const float* sigma_dev)
+{
+    if (!depth_dev || !sigma_dev) { set_error("null map"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const size_t all = (size_t)top_pixels() * n_seq * sizeof(float);
+    const int T = g.top();
+    DVO_HIP(hipMemcpyAsync(ref.depth[T], depth_dev, all, hipMemcpyDeviceToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(ref.sigma[T], sigma_dev, all, hipMemcpyDeviceToDevice, stream));
+    have_init = true;
+    return DVO_OK;
+}
+
+int MonoBatch::odometrize_device(const float* gray_dev)
+{  // system.hpp:44-74 for every sequence
+    if (!gray_dev) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    const int T = g.top(), tw = g.w[T], th = g.h[T], np = tw * th;
+    const int frame_id = ++latest_id;
+    MonoSeq* m = meta.as<MonoSeq>();
+    if (frame_id == 0) {  // system.hpp:49-54: the first frame is the first keyframe of every sequence
+        if (!have_init) {
+            std::vector<float> d, s;
+            default_initial_depth(np, cfg.rng_seed, d, s);
+            DVO_TRY(set_initial_depth(d.data(), s.data()));
+        }
+        build_pyramid(ref, gray_dev, nullptr, nullptr, stream);
+        DVO_HIP(hipMemsetAsync(ref_age.p, 0, ref_age.bytes, stream));
+        redecimate(ref, ref.depth[T], ref.sigma[T], stream);
+        PromoteArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.n_seg = 0; pa.n_seq = n_seq; pa.gray_top = ref.gray[T]; pa.ring_gray = ring_gray.as<float>(); pa.npix = np; pa.R = R;
+        pa.meta = m; pa.all = 1;
+        launch_promote(pa, stream);
+        launch_mono_commit(m, hist_xi.as<float>(), n_seq, R, 1, frame_id, xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), stream);
+        DVO_HIP(hipGetLastError());
+        return DVO_OK;
+    }
+    build_pyramid(frm, gray_dev, nullptr, nullptr, stream);                    // Frame(gray, K, 3, 2)
+    DVO_TRY(trk.track(frm, ref, stream));                                      // system.hpp:57
+    launch_mono_decide(m, trk.state.as<SeqState>(), n_seq, frame_id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
+                       xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), stream);
+    // ---- Mapper::estimate (mapper.cpp:16-33), both branches launched, each sequence takes its own ----
+    {   // need: propagate the reference maps into the frame (mapper.cpp:62-74) ...
+        PropArgs a;
+        a.ref_depth = ref.depth[T]; a.ref_sigma = ref.sigma[T]; a.ref_age = ref_age.as<float>();
+        a.depth = frm.depth[T]; a.sigma = frm.sigma[T]; a.age = frm_age.as<float>();
+        a.owner = owner.as<int>();
+        a.w = tw; a.h = th; a.n_seq = n_seq; a.k = g.k[T]; a.meta = m;
+        memset(&a.pose, 0, sizeof a.pose); a.tz = 0.0f;
+        launch_propagate_batch(a, stream);
+    }
+    {   // !need: stereo update of the reference maps against the keyframe each pixel was born in (mapper.cpp:76-137)
+        AgeTableArgs ta;
+        ta.meta = m; ta.hist_xi = hist_xi.as<float>(); ta.ages = ages.as<AgeEntry>(); ta.n_seq = n_seq; ta.R = R; ta.n_hist = -1;
+        launch_age_table(ta, stream);
+        UpdateArgs a;
+        memset(&a, 0, sizeof a);
+        a.ref_depth = ref.depth[T]; a.ref_sigma = ref.sigma[T]; a.ref_age = ref_age.as<float>();
+        a.obj_gray = frm.gray[T];
+        a.ages = ages.as<AgeEntry>();
+        a.ring_gray = ring_gray.as<float>(); a.gray_table = nullptr; a.meta = m;
+        a.n_seq = n_seq; a.R = R; a.n_hist = 0; a.w = tw; a.h = th; a.crop = cfg.crop_enable; a.obj_id = frame_id;
+        a.clamp_age = 1;
+        a.seed = cfg.rng_seed;
+        a.k = g.k[T];
+        memcpy(a.K9, g.K9[T], sizeof a.K9);
+        launch_depth_update(a, stream);
+    }
+    {   // ... need: the frame becomes the newest keyframe (FrameHistory::push, frame.hpp:151-157)
+        PromoteArgs pa;
+        memset(&pa, 0, sizeof pa);
+        int sgi = 0;
+        for (int l = 0; l < g.levels; l++) { pa.src[sgi] = frm.gray[l]; pa.dst[sgi] = ref.gray[l]; pa.count[sgi] = g.w[l] * g.h[l]; sgi++; }
+        pa.src[sgi] = frm.depth[T]; pa.dst[sgi] = ref.depth[T]; pa.count[sgi] = np; sgi++;
+        pa.src[sgi] = frm.sigma[T]; pa.dst[sgi] = ref.sigma[T]; pa.count[sgi] = np; sgi++;
+        pa.src[sgi] = frm_age.as<float>(); pa.dst[sgi] = ref_age.as<float>(); pa.count[sgi] = np; sgi++;
+        pa.n_seg = sgi; pa.n_seq = n_seq; pa.gray_top = frm.gray[T]; pa.ring_gray = ring_gray.as<float>(); pa.npix = np; pa.R = R;
+        pa.meta = m; pa.all = 0;
+        launch_promote(pa, stream);
+        launch_mono_commit(m, hist_xi.as<float>(), n_seq, R, 0, frame_id, nullptr, nullptr, nullptr, stream);
+    }
+    // Mapper::regularize (mapper.cpp:139-144) of the newest keyframe, then Frame::updateDepthSigma / updateDepth (frame.cpp:39-61):
+    // every level of depth and sigma is a decimation of the top maps, so ONE pass re-derives both pyramids (and 1/depth, the
+    // weight) from the regularized depth and the current sigma -- the same values the reference's two re-decimations leave.
+    launch_regularize_batch(ref.depth[T], ref.sigma[T], tw, th, n_seq, tmp.as<float>(), stream);
+    redecimate(ref, tmp.as<float>(), ref.sigma[T], stream);
+    DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+}  // namespace dvo
+
+using namespace dvo;
+
+extern "C" {
+
+int dvo_batch_create_mono(int n_seq, const float K[9], int width, int height, int ring_keyframes, const dvo_config* cfg, dvo_batch** out)
+{
+    if (!out) return DVO_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    dvo_batch* b = new (std::nothrow) dvo_batch();
+    if (!b) return DVO_ERR_OUT_OF_MEMORY;
+    b->mono.reset(new (std::nothrow) MonoBatch());
+    if (!b->mono) { delete b; return DVO_ERR_OUT_OF_MEMORY; }
+    const int st = b->mono->init(n_seq, K, width, height, ring_keyframes > 0 ? ring_keyframes : 8, cfg);
+    if (st != DVO_OK) { delete b; return st; }
+    *out = b;
+    return DVO_OK;
+}
+
+#define DVO_NEED_MONO(b)                                                                                      \
+    do {                                                                                                      \
+        if (!(b) || !(b)->mono) { set_error("this entry point needs a mono batch (dvo_batch_create_mono)"); return DVO_ERR_BAD_ARGUMENT; } \
+    } while (0)
+
+int dvo_batch_set_initial_depth(dvo_batch* b, const float* depth, const float* sigma)
+{
+    DVO_NEED_MONO(b);
+    return b->mono->set_initial_depth(depth, sigma);
+}
+
+int dvo_batch_set_initial_depth_device(dvo_batch* b, const float* depth_dev, const float* sigma_dev)
+{
+    DVO_NEED_MONO(b);
+    return b->mono->set_initial_depth_device(depth_dev, sigma_dev);
+}
+
+int dvo_batch_odometrize_device(dvo_batch* b, const float* gray_dev)
+{
+    DVO_NEED_MONO(b);
+    return b->mono->odometrize_device(gray_dev);
+}
+
+int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe)
+{
+    DVO_NEED_MONO(b);
+    MonoBatch& M = *b->mono;
+    if (M.latest_id < 0) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(M.device));
+    if (xi_world) DVO_HIP(hipMemcpyAsync(xi_world, M.xi_world.p, sizeof(float) * 6 * (size_t)M.n_seq, hipMemcpyDeviceToHost, M.stream));
+    if (T_world) DVO_HIP(hipMemcpyAsync(T_world, M.T_world.p, sizeof(float) * 16 * (size_t)M.n_seq, hipMemcpyDeviceToHost, M.stream));
+    if (is_keyframe) DVO_HIP(hipMemcpyAsync(is_keyframe, M.is_key.p, sizeof(int) * (size_t)M.n_seq, hipMemcpyDeviceToHost, M.stream));
+    DVO_HIP(hipStreamSynchronize(M.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_copy_world_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev, int* key_dst_dev)
+{
+    DVO_NEED_MONO(b);
+    MonoBatch& M = *b->mono;
+    if (M.latest_id < 0) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(M.device));
+    if (xi_dst_dev) DVO_HIP(hipMemcpyAsync(xi_dst_dev, M.xi_world.p, sizeof(float) * 6 * (size_t)M.n_seq, hipMemcpyDeviceToDevice, M.stream));
+    if (T_dst_dev) DVO_HIP(hipMemcpyAsync(T_dst_dev, M.T_world.p, sizeof(float) * 16 * (size_t)M.n_seq, hipMemcpyDeviceToDevice, M.stream));
+    if (key_dst_dev) DVO_HIP(hipMemcpyAsync(key_dst_dev, M.is_key.p, sizeof(int) * (size_t)M.n_seq, hipMemcpyDeviceToDevice, M.stream));
+    return DVO_OK;
+}
+
+int dvo_batch_keyframe_get(dvo_batch* b, int seq, int level, float* gray, float* depth, float* sigma, float* age, float xi[6], int* id,
+                           int* n_keyframes, int* valid_updates)
+{
+    DVO_NEED_MONO(b);
+    MonoBatch& M = *b->mono;
+    if (seq < 0 || seq >= M.n_seq || level < 0 || level >= M.g.levels) return DVO_ERR_BAD_ARGUMENT;
+    if (M.latest_id < 0) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(M.device));
+    hipStream_t s = M.stream;
+    const size_t n = (size_t)M.g.w[level] * M.g.h[level], off = n * (size_t)seq;
+    if (gray) DVO_HIP(hipMemcpyAsync(gray, M.ref.gray[level] + off, n * 4, hipMemcpyDeviceToHost, s));
+    if (depth) DVO_HIP(hipMemcpyAsync(depth, M.ref.depth[level] + off, n * 4, hipMemcpyDeviceToHost, s));
+    if (sigma) DVO_HIP(hipMemcpyAsync(sigma, M.ref.sigma[level] + off, n * 4, hipMemcpyDeviceToHost, s));
+    if (age) {
+        if (level != M.g.top()) { set_error("age is stored for the top level only"); return DVO_ERR_BAD_ARGUMENT; }
+        DVO_HIP(hipMemcpyAsync(age, M.ref_age.as<float>() + off, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    MonoSeq m;
+    DVO_HIP(hipMemcpyAsync(&m, M.meta.as<MonoSeq>() + seq, sizeof m, hipMemcpyDeviceToHost, s));
+    DVO_HIP(hipStreamSynchronize(s));
+    if (xi) memcpy(xi, m.ref_xi, 6 * sizeof(float));
+    if (id) *id = m.ref_id;
+    if (n_keyframes) *n_keyframes = m.n_total;
+    if (valid_updates) *valid_updates = m.valid_updates;
+    return DVO_OK;
+}
+
+}  // extern "C"

@@ -68,6 +68,8 @@ EXPORTS = [
     "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
     "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
+    "dvo_batch_create_mono", "dvo_batch_set_initial_depth", "dvo_batch_set_initial_depth_device", "dvo_batch_odometrize_device",
+    "dvo_batch_world_poses", "dvo_batch_copy_world_poses_device", "dvo_batch_keyframe_get",
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
     "dvo_op_propagate", "dvo_op_regularize", "dvo_op_depth_update", "dvo_op_se3_exp", "dvo_op_se3_log",
     "dvo_op_se3_concatenate",
@@ -520,3 +522,68 @@ class Batch:
         ms = C.c_float(); px = C.c_uint64()
         _check(lib().dvo_batch_probe_gn(self._p, level, n_launches, C.byref(ms), C.byref(px)))
         return ms.value, px.value
+
+
+class MonoBatch:
+    """n_seq mono sequences per GPU: System::VisualOdometry::odometrize (track + Mapper::estimate + regularize, system.hpp:44-74,
+    src/map/mapper.cpp:16-144) for every sequence per call, keyframe decisions on the device (dvo_batch_create_mono)."""
+
+    def __init__(self, n_seq, K, width, height, ring_keyframes=8, cfg=None):
+        K = f32(K).reshape(9)
+        self.n_seq, self.width, self.height = n_seq, width, height
+        self._p = C.c_void_p()
+        _check(lib().dvo_batch_create_mono(n_seq, fp(K), width, height, ring_keyframes,
+                                           C.byref(cfg) if cfg is not None else None, C.byref(self._p)))
+
+    def close(self):
+        if self._p:
+            lib().dvo_batch_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setInitialDepth(self, depth, sigma):
+        d = f32(depth); s = f32(sigma)
+        assert d.shape == (self.height // 4, self.width // 4)
+        _check(lib().dvo_batch_set_initial_depth(self._p, fp(d), fp(s)))
+
+    def setInitialDepthDevice(self, depth_ptr, sigma_ptr):
+        _check(lib().dvo_batch_set_initial_depth_device(self._p, C.c_void_p(depth_ptr), C.c_void_p(sigma_ptr)))
+
+    def odometrize_device(self, gray_ptr):
+        """Device pointer (int) to [n_seq, H, W] float32 gray frames."""
+        _check(lib().dvo_batch_odometrize_device(self._p, C.c_void_p(gray_ptr)))
+
+    def world_poses(self):
+        xi = np.zeros((self.n_seq, 6), np.float32); T = np.zeros((self.n_seq, 16), np.float32); key = np.zeros(self.n_seq, np.int32)
+        _check(lib().dvo_batch_world_poses(self._p, fp(xi), fp(T), key.ctypes.data_as(C.c_void_p)))
+        return xi, T.reshape(self.n_seq, 4, 4), key.astype(bool)
+
+    def copy_world_poses_device(self, xi_ptr=0, T_ptr=0, key_ptr=0):
+        _check(lib().dvo_batch_copy_world_poses_device(self._p, C.c_void_p(xi_ptr or None), C.c_void_p(T_ptr or None), C.c_void_p(key_ptr or None)))
+
+    def keyframe(self, seq, level=2):
+        sh = ((self.height // 4) >> (2 - level), (self.width // 4) >> (2 - level))
+        g = np.zeros(sh, np.float32); d = np.zeros(sh, np.float32); s = np.zeros(sh, np.float32)
+        a = np.zeros(sh, np.float32) if level == 2 else None
+        xi = np.zeros(6, np.float32); i = C.c_int(); n = C.c_int(); v = C.c_int()
+        _check(lib().dvo_batch_keyframe_get(self._p, seq, level, fp(g), fp(d), fp(s), fp(a) if a is not None else None, fp(xi),
+                                            C.byref(i), C.byref(n), C.byref(v)))
+        return dict(gray=g, depth=d, sigma=s, age=a, xi=xi, id=i.value, n_keyframes=n.value, valid_updates=v.value)
+
+    def last_track_log(self, seq):
+        log = TrackLog()
+        _check(lib().dvo_batch_last_track_log(self._p, seq, C.byref(log)))
+        return log.to_dict()
+
+    def synchronize(self):
+        _check(lib().dvo_batch_synchronize(self._p))
+
+    def profile(self, reset=False):
+        p = GnProfile()
+        _check(lib().dvo_batch_profile(self._p, C.byref(p), 1 if reset else 0))
+        return dict(gn_ms=p.gn_ms, gn_launches=p.gn_launches, gn_pixels=p.gn_pixels, gn_iterations=p.gn_iterations)

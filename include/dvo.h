@@ -154,6 +154,30 @@ int dvo_batch_profile(dvo_batch* b, dvo_gn_profile* out, int reset);
 int dvo_batch_probe_gn(dvo_batch* b, int level, int n_launches, float* avg_ms, uint64_t* pixels_per_launch);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batched MONO pipeline: System::VisualOdometry::odometrize (system.hpp:44-74) = Tracker::track against the newest keyframe +
+ * Map::Mapper::estimate / regularize (src/map/mapper.cpp:16-144), n_seq sequences per call.  The keyframe decision
+ * (Mapper::needNewFrame, mapper.cpp:45-60) is taken per sequence ON THE DEVICE; one call enqueues a fixed launch sequence and
+ * returns.  FrameHistory (include/system/frame.hpp:146-188) is a ring of the newest `ring_keyframes` keyframes per sequence.
+ * Every sequence gives the bits a dvo_vo handle with the same config gives (and, past `ring_keyframes` keyframes, one with
+ * dvo_vo_set_history_limit(ring_keyframes)).
+ * ------------------------------------------------------------------------------------------------ */
+int dvo_batch_create_mono(int n_seq, const float K[9], int width, int height, int ring_keyframes, const dvo_config* cfg, dvo_batch** out);
+/* Initial depth / sigma of the first keyframes (replaces cv::randn, frame.hpp:17-21) at width/4 x height/4: one host map for every
+ * sequence, or device maps [n_seq][height/4][width/4].  Optional; default as dvo_vo. Call before the first frame. */
+int dvo_batch_set_initial_depth(dvo_batch* b, const float* depth, const float* sigma);
+int dvo_batch_set_initial_depth_device(dvo_batch* b, const float* depth_dev, const float* sigma_dev);
+/* odometrize(gray) for every sequence: gray_dev = [n_seq][height][width] float32 in HBM.  Asynchronous on the handle's stream. */
+int dvo_batch_odometrize_device(dvo_batch* b, const float* gray_dev);
+/* world twists [n_seq][6], world poses exp(xi) [n_seq][16] (system.hpp:73) and keyframe flags [n_seq] of the last frame
+ * (synchronises); any pointer may be NULL.  _device: asynchronous device-to-device copies on the handle's stream. */
+int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe);
+int dvo_batch_copy_world_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev, int* key_dst_dev);
+/* the newest keyframe of sequence `seq` (FrameHistory::getRefFrame, frame.hpp:159-166): maps of one pyramid level (age: top level
+ * only), its world twist, id, the number of keyframes the sequence has created and the valid-update count of the last frame */
+int dvo_batch_keyframe_get(dvo_batch* b, int seq, int level, float* gray, float* depth, float* sigma, float* age, float xi[6], int* id,
+                           int* n_keyframes, int* valid_updates);
+
+/* ------------------------------------------------------------------------------------------------
  * Operator level (host pointers): each runs the corresponding HIP kernel once.  Used by the parity
  * tests and reusable on their own.  `dev` is the HIP device ordinal.
  * ------------------------------------------------------------------------------------------------ */
