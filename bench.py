@@ -36,7 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="sequences tracked concurrently per GPU (0 = 4096 for syn640, 128 for syn1080)")
     ap.add_argument("--frames", type=int, default=6, help="distinct frames per sequence kept in HBM (ping-pong order)")
-    ap.add_argument("--workload", default="syn640", choices=["syn640", "syn1080"])
+    ap.add_argument("--workload", default="syn640", choices=["syn640", "syn1080", "syn640-mono"],
+                    help="syn640: sensor-depth tracking (BASELINE configs[1], the headline); syn1080: configs[3]; "
+                         "syn640-mono: mono tracking + inverse-depth filter (configs[2])")
+    ap.add_argument("--ring", type=int, default=8, help="syn640-mono: keyframes kept per sequence")
     ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
     ap.add_argument("--sigma", type=float, default=0.1, help="sensor sigma (src/core/transform.cpp:75)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -102,6 +105,8 @@ def main():
     import dvo_amd as dvo
     from dvo_amd import synth
 
+    if a.workload == "syn640-mono":
+        return main_mono(a, rank, local, world, dev, cdev, rehearse)
     if a.workload == "syn640":
         W, H, K, levels, culls = 640, 480, synth.K_640, 4, 1          # Frame(g,d,s,K,4,1), system.hpp:82
     else:
@@ -406,6 +411,118 @@ def main():
                                "hoisted_value": hoisted_fps, "hoisted_sample": "%d frame pairs, 1 thread, pose hoisted + 6x6 normal equations" % nh,
                                "cpu": _cpu_model()}
     batch.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_mono(a, rank, local, world, dev, cdev, rehearse):
+    """BASELINE configs[2]: 640x480 mono tracking + inverse-depth filter.  One step = every sequence runs
+    System::VisualOdometry::odometrize (system.hpp:44-74) on its next gray frame: 3-level pyramid (160x120 top), Tracker::track
+    against its newest keyframe, then Mapper::estimate (propagate + new keyframe, or stereo update against the keyframe each
+    pixel was born in) and regularize -- dvo_batch_create_mono, keyframe decisions on the device, no host round trip."""
+    import dvo_amd as dvo
+    from dvo_amd import synth
+    if world > 1:
+        import torch.distributed as dist
+    W, H, K = 640, 480, synth.K_640
+    B = a.batch if a.batch > 0 else 4096
+    F = max(2, a.frames)
+    t_gen = time.time()
+    gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
+    chunk = max(1, 96 // F)
+    for b0 in range(0, B, chunk):
+        b1 = min(B, b0 + chunk)
+        Ts = np.stack([synth.trajectory(F, seed=42 + 1000 * rank + b)[f] for b in range(b0, b1) for f in range(F)])
+        g, _ = synth.render_batch(Ts, K, W, H, device=dev)
+        gray[:, b0:b1] = g.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    stream = torch.cuda.current_stream().cuda_stream
+    poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
+    keys_out = torch.zeros((a.steps, B), dtype=torch.int32, device=dev)
+
+    def run(profile):
+        cfg = dvo.default_config(device=local, stream=stream, profile=profile, rng_seed=1)
+        mb = dvo.MonoBatch(B, K, W, H, ring_keyframes=a.ring, cfg=cfg)
+        mb.odometrize_device(gray[0].data_ptr())             # first frame: first keyframe of every sequence (default initial depth)
+        for k in range(a.warmup):
+            mb.odometrize_device(gray[ring_index(1 + k, F)].data_ptr())
+        if profile:
+            mb.profile(reset=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            mb.odometrize_device(gray[ring_index(1 + a.warmup + k, F)].data_ptr())
+            mb.copy_world_poses_device(poses_out[k].data_ptr(), 0, keys_out[k].data_ptr())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return mb, time.perf_counter() - t0
+
+    mb, dt = run(0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log0 = mb.last_track_log(0)
+    kf0 = mb.keyframe(0)
+    vu = [mb.keyframe(b)["valid_updates"] for b in range(min(B, 64))]
+    mb.close()
+    keys = keys_out.float().mean().item()
+    out = {"metric": "tracked frames/sec (640x480 mono: tracking + inverse-depth filter)", "value": B * a.steps * world / dt, "unit": "frames/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SYN-640 mono (stand-in for TUM fr2/desk: no dataset offline), 640x480 gray only, "
+                                  "Frame(gray,K,3,2) pyramid (160x120 top), track + Mapper::estimate + regularize per frame, "
+                                  "the reference's random initial depth N(1.5, 0.5) >= 0.5 (frame.hpp:17-21)",
+                      "sequences_per_gpu": B, "frames_in_hbm_per_sequence": F, "keyframe_ring": a.ring,
+                      "keyframe_fraction_of_timed_frames": keys, "iterations_per_level_seq0": log0["n_iter"],
+                      "keyframes_created_seq0": kf0["n_keyframes"], "mean_valid_updates_last_frame": float(np.mean(vu)),
+                      "poses_finite": bool(torch.isfinite(poses_out).all().item()), "datagen_s": round(t_gen, 2)}}
+    if not a.no_roofline:
+        pb, _ = run(1)
+        pr = pb.profile()
+        pb.close()
+        if pr["gn_launches"] > 0 and pr["gn_ms"] > 0:
+            bpl = GN_BYTES_PER_PIXEL * pr["gn_pixels"] / pr["gn_launches"]
+            mpl = pr["gn_ms"] / pr["gn_launches"]
+            ach = bpl / (mpl * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_track_gn", "avg_launch_us": mpl * 1e3, "launches": pr["gn_launches"],
+                               "algorithmic_bytes_per_launch": bpl, "gn_share_of_step_time": pr["gn_ms"] / (dt * 1e3),
+                               "note": "levels of 40x30 .. 160x120 only: latency-bound launches; the mapping kernels' figures are in "
+                                       "profiles/r02_mono_*"}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        g0 = gray[:, 0].cpu().numpy()
+
+        def cpu(budget):
+            vo = orc.OVO(K, W, H, seed=1, variant=1)
+            rng = np.random.RandomState(0)
+            d0 = np.maximum(rng.normal(1.5, 0.5, (H // 4, W // 4)), 0.5).astype(np.float32)
+            vo.set_initial_depth(d0, np.full_like(d0, 0.5))
+            vo.odometrize(g0[0])
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget:
+                vo.odometrize(g0[ring_index(1 + n, F)]); n += 1
+            return n / (time.perf_counter() - t0), n
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncore = max(1, min(ncpu, 16))
+        one, n1 = cpu(a.cpu_seconds * 0.5)
+        orc.set_threads(ncore)
+        allc, na = cpu(a.cpu_seconds * 0.5)
+        orc.set_threads(1)
+        out["cpu_baseline"] = {"value": allc, "unit": "frames/s", "cores": ncore, "kind": "port",
+                               "sample": "%d frames of sequence 0 through the oracle's VisualOdometry::odometrize ('faithful' tracker variant, "
+                                         "forEach bodies of the tracker row-parallel over %d threads; the mapper loops are sequential)" % (na, ncore),
+                               "one_core": {"value": one, "cores": 1, "sample": "%d frames, 1 thread" % n1}, "cpu": _cpu_model()}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
