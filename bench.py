@@ -40,6 +40,9 @@ def parse():
                     help="syn640: sensor-depth tracking (BASELINE configs[1], the headline); syn1080: configs[3]; "
                          "syn640-mono: mono tracking + inverse-depth filter (configs[2])")
     ap.add_argument("--ring", type=int, default=8, help="syn640-mono: keyframes kept per sequence")
+    ap.add_argument("--input", default="raw", choices=["raw", "float"],
+                    help="what is resident in HBM per frame: raw = u8 gray + u16 depth as a sensor / cv::imread delivers them (loader.cpp:137-147), "
+                         "converted inside the pyramid kernel; float = float32 gray + depth + sigma maps (round 1's form)")
     ap.add_argument("--fixed-iters", type=int, default=0, help="0 = the reference's early exit; N = exactly N per level")
     ap.add_argument("--sigma", type=float, default=0.1, help="sensor sigma (src/core/transform.cpp:75)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -118,9 +121,14 @@ def main():
     B, F = a.batch, max(2, a.frames)
 
     # ---- synthetic sequences rendered straight into HBM: [F][B][H][W] --------------------------------
+    raw = a.input == "raw" and abs(a.sigma - 0.1) < 1e-9   # (raw frames carry the sensor sigma of transform.cpp:75; other sigmas need float maps)
     t_gen = time.time()
-    gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
-    depth = torch.empty_like(gray)
+    if raw:
+        gray8 = torch.empty((F, B, H, W), dtype=torch.uint8, device=dev)
+        depth16 = torch.empty((F, B, H, W), dtype=torch.int16, device=dev)   # (bit pattern of uint16: 1/5000 m units, TUM convention)
+    else:
+        gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty_like(gray)
     gt_poses = []  # world <- camera ground truth of the first sequences (accuracy sample)
     all_poses = []
     for b in range(B):
@@ -133,12 +141,26 @@ def main():
         b1 = min(B, b0 + chunk)
         Ts = np.stack([all_poses[b][f] for b in range(b0, b1) for f in range(F)])
         g, d = synth.render_batch(Ts, K, W, H, device=dev)
-        gray[:, b0:b1] = g.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
-        depth[:, b0:b1] = d.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
+        g = g.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3); d = d.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
+        if raw:
+            gray8[:, b0:b1] = torch.clamp(torch.round(g * 255.0), 0, 255).to(torch.uint8)
+            depth16[:, b0:b1] = torch.clamp(torch.round(d * 5000.0), 0, 65535).to(torch.int32).to(torch.int16)
+        else:
+            gray[:, b0:b1] = g; depth[:, b0:b1] = d
     del all_poses
-    sigma = torch.full_like(gray, a.sigma)
+    if not raw:
+        sigma = torch.full_like(gray, a.sigma)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
+
+    def host_frames(fsel, bsel):
+        """float32 numpy (gray, depth, sigma) of frames fsel x sequences bsel, exactly what the device path computes from the input"""
+        if not raw:
+            return gray[fsel, bsel].cpu().numpy(), depth[fsel, bsel].cpu().numpy(), sigma[fsel, bsel].cpu().numpy()
+        g8 = gray8[fsel, bsel].cpu().numpy(); d16 = depth16[fsel, bsel].cpu().numpy().view(np.uint16)
+        gg = g8.astype(np.float32) * np.float32(1.0 / 255.0)
+        gg[d16 == 0] = np.float32(-2.0)
+        return gg, d16.astype(np.float32) * np.float32(1.0 / 5000.0), np.where(d16 > 0, np.float32(0.1), np.float32(1.0)).astype(np.float32)
 
     stream = torch.cuda.current_stream().cuda_stream
     cfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, track_streams=a.streams,
@@ -153,8 +175,14 @@ def main():
         f = ring_index(k, F)
         if not a.no_prefetch and k >= 1:
             fn = ring_index(k + 1, F)
-            bt.prefetch_device(gray[fn].data_ptr(), depth[fn].data_ptr(), sigma[fn].data_ptr())
-        bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
+            if raw:
+                bt.prefetch_raw_device(gray8[fn].data_ptr(), 1, depth16[fn].data_ptr())
+            else:
+                bt.prefetch_device(gray[fn].data_ptr(), depth[fn].data_ptr(), sigma[fn].data_ptr())
+        if raw:
+            bt.push_raw_device(gray8[f].data_ptr(), 1, depth16[f].data_ptr())
+        else:
+            bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
         if out is not None:
             bt.copy_poses_device(out.data_ptr())
 
@@ -199,6 +227,7 @@ def main():
         "config": {"workload": "SYN-640 (stand-in for TUM fr1/desk: no dataset offline), 640x480, sensor depth, "
                                "frame-to-frame tracking, 4-level pyramid (320x240 top), reference thresholds"
                    if a.workload == "syn640" else "SYN-1080 dense alignment, 5-level pyramid, fixed iterations",
+                   "input": "raw u8 gray + u16 depth (3 B/px), converted inside k_pyramid" if raw else "float32 gray + depth + sigma maps (12 B/px)",
                    "sequences_per_gpu": B, "frames_in_hbm_per_sequence": F, "sigma": a.sigma,
                    "fixed_iterations": a.fixed_iters, "iterations_per_level_seq0": log0["n_iter"],
                    "note": "sigma = 0.1 is the reference's sensor-depth constant (transform.cpp:75): the Gauss-Newton step is 10x over-relaxed "
@@ -235,21 +264,30 @@ def main():
     if a.pcie_steps > 0:
         PB = min(B, 256)  # a bounded sample of the batch: the rate is PCIe bound, pinned host copies of everything are not needed
         hb = dvo.Batch(PB, K, W, H, levels, culls, cfg=cfg)
-        host = [(gray[f, :PB].cpu().pin_memory(), depth[f, :PB].cpu().pin_memory(), sigma[f, :PB].cpu().pin_memory()) for f in range(min(F, 3))]
+        if raw:
+            host = [(gray8[f, :PB].cpu().pin_memory(), depth16[f, :PB].cpu().pin_memory()) for f in range(min(F, 3))]
+        else:
+            host = [(gray[f, :PB].cpu().pin_memory(), depth[f, :PB].cpu().pin_memory(), sigma[f, :PB].cpu().pin_memory()) for f in range(min(F, 3))]
+        xi_host = np.zeros((PB, 6), np.float32)
         def hpush(k):
-            g_, d_, s_ = host[ring_index(k, len(host))]
-            hb.push_host(g_.numpy(), d_.numpy(), s_.numpy())
+            fr = host[ring_index(k, len(host))]
+            if raw:
+                hb.push_raw_host(fr[0].numpy(), fr[1].numpy().view(np.uint16))
+            else:
+                hb.push_host(fr[0].numpy(), fr[1].numpy(), fr[2].numpy())
         hpush(0); hpush(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(a.pcie_steps):
             hpush(2 + k)
+            hb.last_poses()            # D2H of every pose, per step (synchronises)
         hb.synchronize()
         incl = PB * a.pcie_steps / (time.perf_counter() - t1)
         # co-headline (SURVEY.md §8d defines fps "including H2D of each gray frame and D2H of each pose"); `value` is HBM-resident
         out["value_incl_h2d"] = incl
-        out["incl_h2d"] = {"sequences": PB, "frames_streamed_per_sequence": a.pcie_steps, "bytes_per_frame": 3 * 4 * W * H,
-                           "input": "pinned host float32 gray + depth + sigma (dvo_batch_push_host); poses stay in HBM"}
+        out["incl_h2d"] = {"sequences": PB, "frames_streamed_per_sequence": a.pcie_steps, "bytes_per_frame": (3 if raw else 12) * W * H,
+                           "input": ("pinned host u8 gray + u16 depth (dvo_batch_push_raw_host)" if raw else
+                                     "pinned host float32 gray + depth + sigma (dvo_batch_push_host)") + ", every pose read back per step"}
         hb.close()
 
     # ---- roofline of the dominant kernel (k_track_gn): HIP events around every launch of an identical pass ----
@@ -310,7 +348,7 @@ def main():
     # ---- secondary (N = 1 only, a few seconds): the single-sequence drop-in entry points, host frames in, pose out per call --
     # BASELINE configs[2] (tracking + inverse-depth filter) and the latency view of configs[1]; never part of `value`.
     if rank == 0 and world == 1 and a.workload == "syn640" and not a.no_secondary:
-        g0 = gray[:, 0].cpu().numpy(); d0 = depth[:, 0].cpu().numpy(); s0 = sigma[:, 0].cpu().numpy()
+        g0, d0, s0 = host_frames(slice(None), 0)
         n_sec = 40
         vo = dvo.VisualOdometry(K, W, H, cfg=dvo.default_config(device=local))
         for k in range(3):
@@ -343,7 +381,7 @@ def main():
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         ncore = max(1, min(ncpu, 16))      # the box's CPU share for one GPU
         NS = len(gt_poses)
-        gh = gray[:, :NS].cpu().numpy(); dh = depth[:, :NS].cpu().numpy(); sh = sigma[:, :NS].cpu().numpy()  # [F][NS][H][W]
+        gh, dh, sh = host_frames(slice(None), slice(0, NS))  # [F][NS][H][W]
         crop = a.workload == "syn640"
 
         def run(variant, budget):
@@ -430,14 +468,22 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
     B = a.batch if a.batch > 0 else 4096
     F = max(2, a.frames)
     t_gen = time.time()
-    gray = torch.empty((F, B, H, W), dtype=torch.float32, device=dev)
+    raw = a.input == "raw"
+    gray = torch.empty((F, B, H, W), dtype=torch.uint8 if raw else torch.float32, device=dev)
     chunk = max(1, 96 // F)
     for b0 in range(0, B, chunk):
         b1 = min(B, b0 + chunk)
         Ts = np.stack([synth.trajectory(F, seed=42 + 1000 * rank + b)[f] for b in range(b0, b1) for f in range(F)])
         g, _ = synth.render_batch(Ts, K, W, H, device=dev)
-        gray[:, b0:b1] = g.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
+        g = g.reshape(b1 - b0, F, H, W).permute(1, 0, 2, 3)
+        gray[:, b0:b1] = torch.clamp(torch.round(g * 255.0), 0, 255).to(torch.uint8) if raw else g
     torch.cuda.synchronize()
+
+    def odo(mb, f):
+        if raw:
+            mb.odometrize_raw_device(gray[f].data_ptr(), 1)     # u8 gray as cv::imread + cvtColor deliver it, converted in k_pyramid
+        else:
+            mb.odometrize_device(gray[f].data_ptr())
     t_gen = time.time() - t_gen
     stream = torch.cuda.current_stream().cuda_stream
     poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
@@ -446,9 +492,9 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
     def run(profile):
         cfg = dvo.default_config(device=local, stream=stream, profile=profile, rng_seed=1)
         mb = dvo.MonoBatch(B, K, W, H, ring_keyframes=a.ring, cfg=cfg)
-        mb.odometrize_device(gray[0].data_ptr())             # first frame: first keyframe of every sequence (default initial depth)
+        odo(mb, 0)                                           # first frame: first keyframe of every sequence (default initial depth)
         for k in range(a.warmup):
-            mb.odometrize_device(gray[ring_index(1 + k, F)].data_ptr())
+            odo(mb, ring_index(1 + k, F))
         if profile:
             mb.profile(reset=True)
         torch.cuda.synchronize()
@@ -457,7 +503,7 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(a.steps):
-            mb.odometrize_device(gray[ring_index(1 + a.warmup + k, F)].data_ptr())
+            odo(mb, ring_index(1 + a.warmup + k, F))
             mb.copy_world_poses_device(poses_out[k].data_ptr(), 0, keys_out[k].data_ptr())
         torch.cuda.synchronize()
         if world > 1:
@@ -481,6 +527,7 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
            "config": {"workload": "SYN-640 mono (stand-in for TUM fr2/desk: no dataset offline), 640x480 gray only, "
                                   "Frame(gray,K,3,2) pyramid (160x120 top), track + Mapper::estimate + regularize per frame, "
                                   "the reference's random initial depth N(1.5, 0.5) >= 0.5 (frame.hpp:17-21)",
+                      "input": "raw u8 gray (1 B/px), converted inside k_pyramid" if raw else "float32 gray (4 B/px)",
                       "sequences_per_gpu": B, "frames_in_hbm_per_sequence": F, "keyframe_ring": a.ring,
                       "keyframe_fraction_of_timed_frames": keys, "iterations_per_level_seq0": log0["n_iter"],
                       "keyframes_created_seq0": kf0["n_keyframes"], "mean_valid_updates_last_frame": float(np.mean(vu)),
@@ -502,6 +549,8 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
         g0 = gray[:, 0].cpu().numpy()
+        if raw:
+            g0 = g0.astype(np.float32) * np.float32(1.0 / 255.0)
 
         def cpu(budget):
             vo = orc.OVO(K, W, H, seed=1, variant=1)

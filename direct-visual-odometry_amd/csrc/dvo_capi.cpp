@@ -214,14 +214,60 @@ int dvo_batch_push_device(dvo_batch* b, const float* gray, const float* depth, c
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
     DVO_NOT_MONO(b);
-    return b->impl.push_device(gray, depth, sigma);
+    FrameInput in;
+    in.gray = gray; in.depth = depth; in.sigma = sigma;
+    return b->impl.push(in);
 }
 
 int dvo_batch_prefetch_device(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
 {
     if (!b) return DVO_ERR_BAD_ARGUMENT;
     DVO_NOT_MONO(b);
-    return b->impl.prefetch_device(gray, depth, sigma);
+    FrameInput in;
+    in.gray = gray; in.depth = depth; in.sigma = sigma;
+    return b->impl.prefetch(in);
+}
+
+static int raw_input(dvo_batch* b, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, FrameInput& in)
+{
+    if (!b || !rgb || !depth16 || (channels != 1 && channels != 3 && channels != 4)) { set_error("bad raw frame"); return DVO_ERR_BAD_ARGUMENT; }
+    in.rgb = rgb; in.channels = channels; in.depth16 = depth16; in.depth_scale = depth_scale > 0.0f ? depth_scale : 1.0f / 5000.0f;
+    return DVO_OK;
+}
+
+int dvo_batch_push_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
+    FrameInput in;
+    DVO_TRY(raw_input(b, rgb_dev, channels, depth16_dev, depth_scale, in));
+    return b->impl.push(in);
+}
+
+int dvo_batch_prefetch_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
+    FrameInput in;
+    DVO_TRY(raw_input(b, rgb_dev, channels, depth16_dev, depth_scale, in));
+    return b->impl.prefetch(in);
+}
+
+int dvo_batch_push_raw_host(dvo_batch* b, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale)
+{
+    if (!b) return DVO_ERR_BAD_ARGUMENT;
+    DVO_NOT_MONO(b);
+    FrameInput in;
+    DVO_TRY(raw_input(b, rgb, channels, depth16, depth_scale, in));
+    Batch& B = b->impl;
+    DVO_TRY(select_device(B.device));
+    const size_t px = (size_t)B.n_seq * B.g.src_w * B.g.src_h;
+    if (B.in_rgb.bytes < px * (size_t)channels) DVO_TRY(B.in_rgb.alloc(px * (size_t)channels));
+    if (B.in_d16.bytes < px * 2) DVO_TRY(B.in_d16.alloc(px * 2));
+    DVO_HIP(hipMemcpyAsync(B.in_rgb.p, rgb, px * (size_t)channels, hipMemcpyHostToDevice, B.stream));
+    DVO_HIP(hipMemcpyAsync(B.in_d16.p, depth16, px * 2, hipMemcpyHostToDevice, B.stream));
+    in.rgb = B.in_rgb.as<uint8_t>(); in.depth16 = B.in_d16.as<uint16_t>();
+    return B.push(in);
 }
 
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
@@ -235,7 +281,9 @@ int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, con
     DVO_HIP(hipMemcpyAsync(B.in_gray.p, gray, n, hipMemcpyHostToDevice, B.stream));
     DVO_HIP(hipMemcpyAsync(B.in_depth.p, depth, n, hipMemcpyHostToDevice, B.stream));
     DVO_HIP(hipMemcpyAsync(B.in_sigma.p, sigma, n, hipMemcpyHostToDevice, B.stream));
-    return B.push_device(B.in_gray.as<float>(), B.in_depth.as<float>(), B.in_sigma.as<float>());
+    FrameInput in;
+    in.gray = B.in_gray.as<float>(); in.depth = B.in_depth.as<float>(); in.sigma = B.in_sigma.as<float>();
+    return B.push(in);
 }
 
 int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel)

@@ -163,6 +163,27 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
     launch_pyramid(a, fs.n_seq, s);
 }
 
+void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_sigma)
+{
+    if (!in.raw()) { build_pyramid(fs, in.gray, in.depth, in.sigma, s, keep_sigma); return; }
+    PyramidArgs a;
+    memset(&a, 0, sizeof a);
+    a.raw_rgb = in.rgb; a.raw_channels = in.channels; a.raw_depth = in.depth16;
+    a.raw_gray_scale = (float)(1.0 / 255.0); a.raw_depth_scale = in.depth_scale;
+    a.raw_sigma_valid = 0.1f; a.raw_sigma_invalid = 1.0f; a.raw_invalidate_gray = 1;   // transform.cpp:60-76
+    a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
+    const bool dep = in.depth16 != nullptr;
+    for (int l = 0; l < fs.g.levels; l++) {
+        a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
+        a.dst[0][l] = fs.gray[l];
+        a.dst[1][l] = dep ? fs.depth[l] : nullptr;
+        a.dst[2][l] = (dep && keep_sigma) ? fs.sigma[l] : nullptr;
+    }
+    a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
+    if (dep) fuse_prep(a, fs);
+    launch_pyramid(a, fs.n_seq, s);
+}
+
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s)
 {  // level i = cullImage(top, levels-1-i); the top level itself is the map handed in (frame.cpp:39-61)
     PyramidArgs a;
@@ -688,25 +709,26 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
 }
 
 int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
-{  // the same call fed with raw sensor frames: u8 gray/RGB(A) + u16 depth are converted on the device (k_ingest)
+{  // the same call fed with raw sensor frames: u8 gray/RGB(A) + u16 depth, converted on the device while the pyramid is built
     if (!rgb || !depth16 || !T_rel || (channels != 1 && channels != 3 && channels != 4)) { set_error("bad raw frame"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     const size_t px = (size_t)w * h;
     if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
     DVO_HIP(hipMemcpyAsync(raw_rgb.p, rgb, px * (size_t)channels, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(raw_depth.p, depth16, px * 2, hipMemcpyHostToDevice, stream));
-    launch_ingest(raw_rgb.as<uint8_t>(), channels, raw_depth.as<uint16_t>(), (int)px, depth_scale, 0.1f, 1.0f, 1,
-                  in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
-    return odometrize_depth_staged(T_rel);
+    FrameInput in;
+    in.rgb = raw_rgb.as<uint8_t>(); in.channels = channels; in.depth16 = raw_depth.as<uint16_t>(); in.depth_scale = depth_scale;
+    return odometrize_depth_staged(T_rel, &in);
 }
 
-int VisualOdometry::odometrize_depth_staged(float T_rel[16])
+int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* raw)
 {
     if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
     if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
     Keyframe& frame = *depth_cur;
     frame.id = ++latest_id;
-    build_pyramid(frame.fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
+    if (raw) build_pyramid(frame.fs, *raw, stream);
+    else build_pyramid(frame.fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
     const float z[6] = {0, 0, 0, 0, 0, 0};
     if (!depth_ref) {  // system.hpp:83-86
         for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
@@ -764,37 +786,37 @@ int Batch::init(int n, const float K9[9], int w, int h, int levels, int culls, c
 // Builds the pyramids of a frame that will be handed to push_device later (call order per step: prefetch(k+1); push(k)) on the
 // side stream.  The set it builds into may be the reference of the tracking queued last: the build waits for that tracking --
 // not for anything queued afterwards -- and then runs beside the tracking of frame k.
-int Batch::prefetch_device(const float* gray, const float* depth, const float* sigma)
+int Batch::prefetch(const FrameInput& in)
 {
-    if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    if (!in.key0() || !in.has_depth()) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     const int slot = free_slot();
     if (npre >= 2 || slot < 0) { set_error("dvo_batch_prefetch_device: two prefetched frames are already waiting for their push"); return DVO_ERR_NOT_READY; }
     if (tracked_once) DVO_HIP(hipStreamWaitEvent(pstream, ev_last_track, 0));
-    build_pyramid(fs[slot], gray, depth, sigma, pstream, /*keep_sigma=*/false);
+    build_pyramid(fs[slot], in, pstream, /*keep_sigma=*/false);
     DVO_HIP(hipEventRecord(ev_built[slot], pstream));
     preq[npre] = slot;
-    pre_key[npre][0] = gray; pre_key[npre][1] = depth; pre_key[npre][2] = sigma;
+    pre_key[npre][0] = in.key0(); pre_key[npre][1] = in.key1();
     npre++;
     DVO_HIP(hipGetLastError());
     return DVO_OK;
 }
 
-int Batch::push_device(const float* gray, const float* depth, const float* sigma)
+int Batch::push(const FrameInput& in)
 {
-    if (!gray || !depth || !sigma) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    if (!in.key0() || !in.has_depth()) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     int target;
-    if (npre > 0 && pre_key[0][0] == gray && pre_key[0][1] == depth && pre_key[0][2] == sigma) {
-        target = preq[0];                                   // built by prefetch_device: the tracker waits for that build
+    if (npre > 0 && pre_key[0][0] == in.key0() && pre_key[0][1] == in.key1()) {
+        target = preq[0];                                   // built by prefetch: the tracker waits for that build
         DVO_HIP(hipStreamWaitEvent(stream, ev_built[target], 0));
         preq[0] = preq[1];
-        for (int i = 0; i < 3; i++) pre_key[0][i] = pre_key[1][i];
+        for (int i = 0; i < 2; i++) pre_key[0][i] = pre_key[1][i];
         npre--;
     } else {
         target = (cur < 0 && npre == 0) ? 0 : free_slot();
         if (target < 0) { set_error("dvo_batch_push_device: the frames prefetched must be pushed first, in order"); return DVO_ERR_BAD_ARGUMENT; }
-        build_pyramid(fs[target], gray, depth, sigma, stream, /*keep_sigma=*/false);  // Frame(gray,depth,sigma,K,levels,culls)
+        build_pyramid(fs[target], in, stream, /*keep_sigma=*/false);  // Frame(gray,depth,sigma,K,levels,culls)
     }
     if (cur >= 0) {
         DVO_TRY(trk.track(fs[target], fs[cur], stream));    // system.hpp:88

@@ -72,6 +72,17 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
 // Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
 // keep_sigma = false: the sigma pyramid is only folded into `wgt`, not stored (frame-to-frame tracking never reads it again)
 void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma = true);
+// One frame of every sequence as handed over by the caller: float maps (gray [+ depth + sigma]) or raw sensor frames
+// (u8 gray / RGB / RGBA [+ u16 depth], converted while the pyramid is built: loader.cpp:55-60,137-147, transform.cpp:60-76).
+struct FrameInput {
+    const float* gray = nullptr; const float* depth = nullptr; const float* sigma = nullptr;
+    const uint8_t* rgb = nullptr; int channels = 0; const uint16_t* depth16 = nullptr; float depth_scale = 1.0f / 5000.0f;
+    bool raw() const { return rgb != nullptr; }
+    const void* key0() const { return raw() ? (const void*)rgb : (const void*)gray; }
+    const void* key1() const { return raw() ? (const void*)depth16 : (const void*)depth; }
+    bool has_depth() const { return raw() ? depth16 != nullptr : (depth != nullptr && sigma != nullptr); }
+};
+void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_sigma = true);
 // Frame::updateDepthSigma / updateDepth (frame.cpp:39-61): re-decimate from a top-level map (may alias the top level)
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s);
 
@@ -156,7 +167,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int odometrize(const float* gray, float T_world[16], int* is_key);
     int odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16]);
     int odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16]);
-    int odometrize_depth_staged(float T_rel[16]);  // frame already in in_gray / in_depth / in_sigma
+    int odometrize_depth_staged(float T_rel[16], const struct FrameInput* raw = nullptr);  // frame already staged on the device
     DevBuf raw_rgb, raw_depth;
     int init_keyframe(const float* gray, const float* depth, const float* sigma);
     int map_propagate(Keyframe& frame, const Keyframe& ref);
@@ -181,12 +192,13 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
     // prefetch_device is called: "prefetch(k+1); push(k)" finds frame k (prefetched one step earlier) still waiting.
     int preq[2] = {-1, -1};
     int npre = 0;
-    const float* pre_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    const void* pre_key[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipStream_t pstream = nullptr;
     hipEvent_t ev_last_track = nullptr, ev_built[3] = {nullptr, nullptr, nullptr};
     bool tracked_once = false;
     bool have_poses = false;
     DevBuf in_gray, in_depth, in_sigma;  // staging for push_host
+    DevBuf in_rgb, in_d16;               // staging for push_raw_host
     ~Batch();
     int init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c);
     int free_slot() const  // a frame set that is neither the reference nor waiting prefetched (-1: none)
@@ -195,8 +207,8 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
             if (i != cur && !(npre > 0 && preq[0] == i) && !(npre > 1 && preq[1] == i)) return i;
         return -1;
     }
-    int prefetch_device(const float* gray, const float* depth, const float* sigma);
-    int push_device(const float* gray, const float* depth, const float* sigma);
+    int prefetch(const FrameInput& in);
+    int push(const FrameInput& in);
 };
 
 int select_device(int device);
@@ -222,7 +234,7 @@ struct MonoBatch {
     ~MonoBatch();
     int set_initial_depth(const float* depth_host, const float* sigma_host);              // one map, broadcast to every sequence
     int set_initial_depth_device(const float* depth_dev, const float* sigma_dev);         // [n_seq][th][tw]
-    int odometrize_device(const float* gray_dev);                                          // [n_seq][h][w]
+    int odometrize(const FrameInput& in);                                                  // gray [n_seq][h][w] float, or raw u8
     int top_pixels() const { return g.w[g.top()] * g.h[g.top()]; }
 };
 

@@ -28,6 +28,13 @@ struct PyramidArgs {
     float* wgt[DVO_MAX_LEVELS];
     float step[DVO_MAX_LEVELS];
     float sigma_min, sigma_max;
+    // optional raw sensor input (raw_rgb != nullptr; src[] is then ignored): the conversion of k_ingest (loader.cpp:55-60,137-147,
+    // transform.cpp:60-76) is applied to the 1/4^culls of the pixels the pyramid keeps, while they are loaded -- the float maps
+    // of the full frame are never materialised.  raw_depth == nullptr: gray only (mono).
+    const uint8_t* raw_rgb;      // [n_seq][src_h][src_w][raw_channels], channels 1 (gray), 3 (R,G,B) or 4 (R,G,B,A)
+    const uint16_t* raw_depth;   // [n_seq][src_h][src_w]
+    int raw_channels, raw_invalidate_gray;
+    float raw_gray_scale, raw_depth_scale, raw_sigma_valid, raw_sigma_invalid;
 };
 
 struct GnArgs {

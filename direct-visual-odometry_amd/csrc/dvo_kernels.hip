@@ -146,11 +146,32 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
     split_index(i, tw, a.inv_tw, x, y);
     const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << a.culls) * a.src_w + (x << a.culls);
     float raw[3] = {0.0f, 0.0f, 0.0f};
+    bool have[3];
+    if (a.raw_rgb != nullptr) {  // raw sensor frame: convert exactly as k_ingest does (same float operations), only the kept pixels
+        unsigned g8;
+        if (a.raw_channels == 1) {
+            g8 = __builtin_nontemporal_load(a.raw_rgb + src_off);
+        } else {
+            const uint8_t* p = a.raw_rgb + src_off * (size_t)a.raw_channels;
+            g8 = ((unsigned)p[0] * 4899u + (unsigned)p[1] * 9617u + (unsigned)p[2] * 1868u + 8192u) >> 14;
+        }
+        raw[0] = (float)g8 * a.raw_gray_scale;
+        have[0] = true; have[1] = have[2] = a.raw_depth != nullptr;
+        if (a.raw_depth != nullptr) {
+            const unsigned d = __builtin_nontemporal_load(a.raw_depth + src_off);
+            raw[1] = (float)d * a.raw_depth_scale;
+            raw[2] = d > 0 ? a.raw_sigma_valid : a.raw_sigma_invalid;
+            if (a.raw_invalidate_gray && d == 0) raw[0] = kInvalid;
+        }
+    } else {
 #pragma unroll
-    for (int m = 0; m < 3; m++)
-        if (a.src[m] != nullptr) raw[m] = __builtin_nontemporal_load(a.src[m] + src_off);  // read once: streamed past the caches; the three loads are in flight together
+        for (int m = 0; m < 3; m++) {
+            have[m] = a.src[m] != nullptr;
+            if (have[m]) raw[m] = __builtin_nontemporal_load(a.src[m] + src_off);  // read once: streamed past the caches; the three loads are in flight together
+        }
+    }
     // the reference-frame constants of k_prep_ref, written while depth and sigma are in registers (needs both maps)
-    const bool prep = a.iz[0] != nullptr && a.src[1] != nullptr && a.src[2] != nullptr;
+    const bool prep = a.iz[0] != nullptr && have[1] && have[2];
     for (int t = 0; t < a.levels; t++) {
         const int msk = (1 << t) - 1;
         if ((x & msk) | (y & msk)) break;  // level t below the top keeps pixels whose coordinates are multiples of 2^t
@@ -162,11 +183,103 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
         for (int m = 0; m < 3; m++) {
             // top level: cullImage(src, culls); culls == 0 aliases the input (convert.cpp:9-10), no pass_valid
             val[m] = (t == 0 && a.culls == 0) ? raw[m] : pass_valid(raw[m]);
-            if (a.src[m] != nullptr && a.dst[m][l] != nullptr) __builtin_nontemporal_store(val[m], a.dst[m][l] + o);  // (a map may be consumed without being kept; next read: a whole tracking step later)
+            if (have[m] && a.dst[m][l] != nullptr) __builtin_nontemporal_store(val[m], a.dst[m][l] + o);  // (a map may be consumed without being kept; next read: a whole tracking step later)
         }
         if (prep) {
             __builtin_nontemporal_store(1.0f / val[1], a.iz[l] + o);
             __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]), a.wgt[l] + o);
+        }
+    }
+}
+
+// k_pyramid_raw4: the raw-sensor form of k_pyramid for 1-channel u8 gray (+ u16 depth) with CULLS = 1 or 2, four kept pixels
+// per thread.  The scalar form spends one byte / short load per lane (a full vector-memory instruction for 1-2 useful bytes and
+// half-empty sectors); here a thread owns 4 consecutive top-level pixels = 4 << CULLS source pixels of one row, fetched by one or
+// two dwordx2/x4 loads, and writes its four top-level values per map as one dwordx4 store.  Same conversions, same float
+// operations as k_ingest + k_pyramid: bit-identical (tests/test_frontend_and_eval.py).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int CULLS>
+__global__ void __launch_bounds__(256) k_pyramid_raw4(PyramidArgs a)
+{
+    const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1], gw = tw >> 2;
+    const unsigned bps = ((unsigned)(gw * th) + 255u) >> 8;
+    const int seq = (int)(blockIdx.x / bps);
+    const int gi = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + threadIdx.x;
+    if (gi >= gw * th) return;
+    const int y = gi / gw, x0 = (gi - y * gw) << 2;
+    const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << CULLS) * a.src_w + ((size_t)x0 << CULLS);
+    constexpr int GW = 1 << CULLS;       // 32-bit words of gray bytes this thread reads (2 or 4)
+    unsigned gwords[GW], dwords[2 * GW];
+    const bool dep = a.raw_depth != nullptr;
+    {
+        const unsigned* gp = reinterpret_cast<const unsigned*>(a.raw_rgb + src_off);
+        if constexpr (CULLS == 1) { const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(gp)); gwords[0] = v.x; gwords[1] = v.y; }
+        else { const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gp)); gwords[0] = v.x; gwords[1] = v.y; gwords[2] = v.z; gwords[3] = v.w; }
+        if (dep) {
+            const u32x4* dp = reinterpret_cast<const u32x4*>(a.raw_depth + src_off);
+#pragma unroll
+            for (int q = 0; q < GW / 2; q++) {
+                const u32x4 v = __builtin_nontemporal_load(dp + q);
+                dwords[4 * q] = v.x; dwords[4 * q + 1] = v.y; dwords[4 * q + 2] = v.z; dwords[4 * q + 3] = v.w;
+            }
+        }
+    }
+    float raw[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int si = k << CULLS;                                            // source pixel of kept pixel k
+        const unsigned g8 = (gwords[si >> 2] >> ((si & 3) * 8)) & 0xffu;
+        raw[k][0] = (float)g8 * a.raw_gray_scale;
+        raw[k][1] = 0.0f; raw[k][2] = 0.0f;
+        if (dep) {
+            const unsigned d = (dwords[si >> 1] >> ((si & 1) * 16)) & 0xffffu;
+            raw[k][1] = (float)d * a.raw_depth_scale;
+            raw[k][2] = d > 0 ? a.raw_sigma_valid : a.raw_sigma_invalid;
+            if (a.raw_invalidate_gray && d == 0) raw[k][0] = kInvalid;
+        }
+    }
+    const bool prep = a.iz[0] != nullptr && dep;
+    // top level (t = 0): cullImage(src, CULLS >= 1) -> pass_valid; four values per map, one 16-byte store
+    {
+        const int l = a.levels - 1;
+        const size_t o = (size_t)seq * tw * th + (size_t)y * tw + x0;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v[3], izv, wgv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float g = pass_valid(raw[k][0]), d = pass_valid(raw[k][1]), sg = pass_valid(raw[k][2]);
+            v[0][k] = g; v[1][k] = d; v[2][k] = sg;
+            izv[k] = 1.0f / d;
+            wgv[k] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, sg);
+        }
+        __builtin_nontemporal_store(v[0], reinterpret_cast<f4*>(a.dst[0][l] + o));
+        if (dep && a.dst[1][l]) __builtin_nontemporal_store(v[1], reinterpret_cast<f4*>(a.dst[1][l] + o));
+        if (dep && a.dst[2][l]) __builtin_nontemporal_store(v[2], reinterpret_cast<f4*>(a.dst[2][l] + o));
+        if (prep) {
+            __builtin_nontemporal_store(izv, reinterpret_cast<f4*>(a.iz[l] + o));
+            __builtin_nontemporal_store(wgv, reinterpret_cast<f4*>(a.wgt[l] + o));
+        }
+    }
+    for (int t = 1; t < a.levels; t++) {   // lower levels: pixels whose coordinates are multiples of 2^t
+        const int msk = (1 << t) - 1;
+        if (y & msk) break;
+        const int l = a.levels - 1 - t, ly = y >> t;
+        if (ly >= a.h[l]) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + k;
+            if (x & msk) continue;
+            const int lx = x >> t;
+            if (lx >= a.w[l]) continue;
+            const size_t o = (size_t)seq * a.w[l] * a.h[l] + (size_t)ly * a.w[l] + lx;
+            const float g = pass_valid(raw[k][0]), d = pass_valid(raw[k][1]), sg = pass_valid(raw[k][2]);
+            __builtin_nontemporal_store(g, a.dst[0][l] + o);
+            if (dep && a.dst[1][l]) __builtin_nontemporal_store(d, a.dst[1][l] + o);
+            if (dep && a.dst[2][l]) __builtin_nontemporal_store(sg, a.dst[2][l] + o);
+            if (prep) {
+                __builtin_nontemporal_store(1.0f / d, a.iz[l] + o);
+                __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, sg), a.wgt[l] + o);
+            }
         }
     }
 }
@@ -1101,6 +1214,22 @@ static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s)
 {
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
+    // raw 1-channel frames with the usual alignment: four kept pixels per thread, wide loads and stores
+    const bool vec = a.raw_rgb != nullptr && a.raw_channels == 1 && (a.culls == 1 || a.culls == 2) && (tw % 4) == 0 && (a.src_w % (4 << a.culls)) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.raw_rgb) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.raw_depth) % 16) == 0;
+    bool aligned = true;   // the 16-byte top-level stores
+    {
+        const int T = a.levels - 1;
+        const void* tops[5] = {a.dst[0][T], a.dst[1][T], a.dst[2][T], a.iz[T], a.wgt[T]};
+        for (const void* p : tops) aligned = aligned && (reinterpret_cast<uintptr_t>(p) % 16) == 0;
+        aligned = aligned && ((size_t)tw * th % 4) == 0;
+    }
+    if (vec && aligned) {
+        const dim3 grid(cdiv((tw >> 2) * th, 256) * (unsigned)n_seq);
+        if (a.culls == 1) hipLaunchKernelGGL(k_pyramid_raw4<1>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_pyramid_raw4<2>, grid, dim3(256), 0, s, a);
+        return;
+    }
     hipLaunchKernelGGL(k_pyramid, dim3(cdiv(tw * th, 256) * (unsigned)n_seq), dim3(256), 0, s, a);
 }
 

@@ -70,9 +70,11 @@ int MonoBatch::set_initial_depth_device(const float* depth_dev, const float* sig
     return DVO_OK;
 }
 
-int MonoBatch::odometrize_device(const float* gray_dev)
+int MonoBatch::odometrize(const FrameInput& in)
 {  // system.hpp:44-74 for every sequence
-    if (!gray_dev) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    if (!in.key0() || (in.raw() && in.channels != 1 && in.channels != 3 && in.channels != 4)) { set_error("null device pointer / bad channel count"); return DVO_ERR_BAD_ARGUMENT; }
+    FrameInput gin = in;          // mono: gray only
+    gin.depth = nullptr; gin.sigma = nullptr; gin.depth16 = nullptr;
     DVO_TRY(select_device(device));
     const int T = g.top(), tw = g.w[T], th = g.h[T], np = tw * th;
     const int frame_id = ++latest_id;
@@ -83,7 +85,7 @@ int MonoBatch::odometrize_device(const float* gray_dev)
             default_initial_depth(np, cfg.rng_seed, d, s);
             DVO_TRY(set_initial_depth(d.data(), s.data()));
         }
-        build_pyramid(ref, gray_dev, nullptr, nullptr, stream);
+        build_pyramid(ref, gin, stream);
         DVO_HIP(hipMemsetAsync(ref_age.p, 0, ref_age.bytes, stream));
         redecimate(ref, ref.depth[T], ref.sigma[T], stream);
         PromoteArgs pa;
@@ -95,7 +97,7 @@ int MonoBatch::odometrize_device(const float* gray_dev)
         DVO_HIP(hipGetLastError());
         return DVO_OK;
     }
-    build_pyramid(frm, gray_dev, nullptr, nullptr, stream);                    // Frame(gray, K, 3, 2)
+    build_pyramid(frm, gin, stream);                                           // Frame(gray, K, 3, 2)
     DVO_TRY(trk.track(frm, ref, stream));                                      // system.hpp:57
     launch_mono_decide(m, trk.state.as<SeqState>(), n_seq, frame_id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
                        xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), stream);
@@ -188,7 +190,17 @@ int dvo_batch_set_initial_depth_device(dvo_batch* b, const float* depth_dev, con
 int dvo_batch_odometrize_device(dvo_batch* b, const float* gray_dev)
 {
     DVO_NEED_MONO(b);
-    return b->mono->odometrize_device(gray_dev);
+    FrameInput in;
+    in.gray = gray_dev;
+    return b->mono->odometrize(in);
+}
+
+int dvo_batch_odometrize_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels)
+{
+    DVO_NEED_MONO(b);
+    FrameInput in;
+    in.rgb = rgb_dev; in.channels = channels;
+    return b->mono->odometrize(in);
 }
 
 int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe)

@@ -68,6 +68,7 @@ EXPORTS = [
     "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
     "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
+    "dvo_batch_push_raw_device", "dvo_batch_prefetch_raw_device", "dvo_batch_push_raw_host", "dvo_batch_odometrize_raw_device",
     "dvo_batch_create_mono", "dvo_batch_set_initial_depth", "dvo_batch_set_initial_depth_device", "dvo_batch_odometrize_device",
     "dvo_batch_world_poses", "dvo_batch_copy_world_poses_device", "dvo_batch_keyframe_get",
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
@@ -496,6 +497,19 @@ class Batch:
         assert g.shape == (self.n_seq, self.height, self.width)
         _check(lib().dvo_batch_push_host(self._p, fp(g), fp(d), fp(s)))
 
+    def push_raw_device(self, rgb_ptr, channels, depth16_ptr, depth_scale=1.0 / 5000.0):
+        """Device pointers to raw frames: [n_seq, H, W(, C)] uint8 and [n_seq, H, W] uint16 (converted inside the pyramid kernel)."""
+        _check(lib().dvo_batch_push_raw_device(self._p, C.c_void_p(rgb_ptr), int(channels), C.c_void_p(depth16_ptr), C.c_float(depth_scale)))
+
+    def prefetch_raw_device(self, rgb_ptr, channels, depth16_ptr, depth_scale=1.0 / 5000.0):
+        _check(lib().dvo_batch_prefetch_raw_device(self._p, C.c_void_p(rgb_ptr), int(channels), C.c_void_p(depth16_ptr), C.c_float(depth_scale)))
+
+    def push_raw_host(self, rgb_u8, depth_u16, depth_scale=1.0 / 5000.0):
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8); d16 = np.ascontiguousarray(depth_u16, np.uint16)
+        ch = 1 if rgb.ndim == 3 else rgb.shape[3]
+        assert rgb.shape[:3] == (self.n_seq, self.height, self.width) and d16.shape == (self.n_seq, self.height, self.width)
+        _check(lib().dvo_batch_push_raw_host(self._p, rgb.ctypes.data_as(C.c_void_p), ch, d16.ctypes.data_as(C.c_void_p), C.c_float(depth_scale)))
+
     def last_poses(self):
         xi = np.zeros((self.n_seq, 6), np.float32); T = np.zeros((self.n_seq, 16), np.float32)
         _check(lib().dvo_batch_last_poses(self._p, fp(xi), fp(T)))
@@ -557,6 +571,10 @@ class MonoBatch:
     def odometrize_device(self, gray_ptr):
         """Device pointer (int) to [n_seq, H, W] float32 gray frames."""
         _check(lib().dvo_batch_odometrize_device(self._p, C.c_void_p(gray_ptr)))
+
+    def odometrize_raw_device(self, rgb_ptr, channels):
+        """Device pointer (int) to [n_seq, H, W(, C)] uint8 frames (gray / RGB / RGBA)."""
+        _check(lib().dvo_batch_odometrize_raw_device(self._p, C.c_void_p(rgb_ptr), int(channels)))
 
     def world_poses(self):
         xi = np.zeros((self.n_seq, 6), np.float32); T = np.zeros((self.n_seq, 16), np.float32); key = np.zeros(self.n_seq, np.int32)

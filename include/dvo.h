@@ -134,6 +134,14 @@ int dvo_batch_push_device(dvo_batch* b, const float* gray_dev, const float* dept
 int dvo_batch_prefetch_device(dvo_batch* b, const float* gray_dev, const float* depth_dev, const float* sigma_dev);
 /* same, from host memory (adds the H2D copies) */
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma);
+/* The same three calls fed with RAW sensor frames, [n_seq][height][width] u8 gray / R,G,B / R,G,B,A (channels 1 / 3 / 4) + u16
+ * depth: what cv::imread delivers before Loader::getNormalizedImages converts it (src/core/loader.cpp:137-147).  The conversion
+ * (BGR2GRAY fixed-point luma, 1/255, depth * depth_scale [0 = 1/5000], sigma 0.1 / 1.0 and INVALID gray where depth == 0:
+ * src/core/transform.cpp:60-76) runs inside the pyramid kernel on the pixels the pyramid keeps: 3 B/px (gray) instead of 12 B/px
+ * cross PCIe and are read from HBM, and the results are bit-identical to dvo_op_ingest + the float entry points. */
+int dvo_batch_push_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale);
+int dvo_batch_prefetch_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale);
+int dvo_batch_push_raw_host(dvo_batch* b, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale);
 /* relative twists [n_seq][6] and 4x4 relative poses [n_seq][16] of the last push (synchronises). NULL = skip */
 int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel);
 /* asynchronous device-to-device copy of the last push's poses (on the handle's stream): pose-out without a
@@ -168,6 +176,8 @@ int dvo_batch_set_initial_depth(dvo_batch* b, const float* depth, const float* s
 int dvo_batch_set_initial_depth_device(dvo_batch* b, const float* depth_dev, const float* sigma_dev);
 /* odometrize(gray) for every sequence: gray_dev = [n_seq][height][width] float32 in HBM.  Asynchronous on the handle's stream. */
 int dvo_batch_odometrize_device(dvo_batch* b, const float* gray_dev);
+/* same from raw u8 frames [n_seq][height][width][channels] (channels 1 / 3 / 4), converted inside the pyramid kernel */
+int dvo_batch_odometrize_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels);
 /* world twists [n_seq][6], world poses exp(xi) [n_seq][16] (system.hpp:73) and keyframe flags [n_seq] of the last frame
  * (synchronises); any pointer may be NULL.  _device: asynchronous device-to-device copies on the handle's stream. */
 int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe);

@@ -209,6 +209,87 @@ def test_odometrize_raw_equals_float_path():
     vo_b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3])
+def test_batch_raw_push_equals_float_push(channels):
+    """dvo_batch_push_raw_{host,device} (u8 gray / RGB + u16 depth, converted inside k_pyramid on the pixels the pyramid keeps) against
+    dvo_op_ingest + dvo_batch_push_host on the same frames: poses and track logs bit-identical, with and without the look-ahead."""
+    import torch
+    from util import K640, frames
+    g, d, s, _ = frames(4, sigma=0.1)
+    B = 5
+    rng = np.random.RandomState(3)
+    raw_rgb, raw_d16, fl = [], [], []
+    for k in range(4):
+        rr, dd, ff = [], [], []
+        for b in range(B):
+            g8 = np.clip(np.rint(g[(k + b) % 4] * 255), 0, 255).astype(np.uint8)
+            if channels == 3:
+                rgb = np.stack([g8, np.roll(g8, 1, axis=1), np.roll(g8, 2, axis=0)], axis=-1)   # three different channels
+            else:
+                rgb = g8
+            d16 = np.clip(np.rint(d[(k + b) % 4] * 5000), 0, 65535).astype(np.uint16)
+            d16[rng.uniform(size=d16.shape) < 0.02] = 0
+            rr.append(rgb); dd.append(d16); ff.append(dvo.ingest(rgb, d16))
+        raw_rgb.append(np.stack(rr)); raw_d16.append(np.stack(dd)); fl.append(ff)
+    def run(mode):
+        bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        out = []
+        if mode == "device":
+            dev = torch.device("cuda", 0)
+            tr = [torch.from_numpy(a).to(dev) for a in raw_rgb]; td = [torch.from_numpy(a.view(np.int16)).to(dev) for a in raw_d16]
+            torch.cuda.synchronize()
+        for k in range(4):
+            if mode == "float":
+                bt.push_host(np.stack([f[0] for f in fl[k]]), np.stack([f[1] for f in fl[k]]), np.stack([f[2] for f in fl[k]]))
+            elif mode == "host":
+                bt.push_raw_host(raw_rgb[k], raw_d16[k])
+            else:
+                if 1 <= k < 3:
+                    bt.prefetch_raw_device(tr[k + 1].data_ptr(), channels, td[k + 1].data_ptr())
+                bt.push_raw_device(tr[k].data_ptr(), channels, td[k].data_ptr())
+            if k > 0:
+                out.append((bt.last_poses()[0].copy(), [bt.last_track_log(b)["residual"] for b in range(B)]))
+        bt.close()
+        return out
+    ref = run("float")
+    assert np.abs(ref[0][0]).max() > 1e-5
+    for mode in ("host", "device"):
+        got = run(mode)
+        for (xa, la), (xb, lb) in zip(ref, got):
+            np.testing.assert_array_equal(xa, xb)
+            for b in range(B):
+                for l in range(4):
+                    np.testing.assert_array_equal(la[b][l], lb[b][l])
+
+
+@pytest.mark.gpu
+def test_mono_batch_raw_equals_float():
+    import torch
+    from util import K640, frames
+    g = frames(4, sigma=0.1)[0]
+    B = 3
+    dev = torch.device("cuda", 0)
+    res = []
+    for raw in (False, True):
+        mb = dvo.MonoBatch(B, K640, 640, 480, cfg=dvo.default_config(rng_seed=2))
+        out = []
+        for k in range(4):
+            g8 = np.stack([np.clip(np.rint(g[(k + b) % 4] * 255), 0, 255).astype(np.uint8) for b in range(B)])
+            if raw:
+                t = torch.from_numpy(g8).to(dev); torch.cuda.synchronize()
+                mb.odometrize_raw_device(t.data_ptr(), 1)
+            else:
+                t = torch.from_numpy(np.stack([dvo.ingest(g8[b]) for b in range(B)])).to(dev); torch.cuda.synchronize()
+                mb.odometrize_device(t.data_ptr())
+            out.append(mb.world_poses()[1].copy())
+        out.append(mb.keyframe(1)["depth"])
+        mb.close()
+        res.append(out)
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
 # ---------------------------------------------------------------- whole-trajectory agreement (BASELINE.json: ATE within 1e-3 m of the reference)
 @pytest.mark.gpu
 def test_trajectory_ate_gpu_vs_oracle_on_synthetic_ground_truth():
