@@ -183,23 +183,14 @@ __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ de
 }
 
 // ------------------------------------------------------------------------------------------------
-// Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per reference pixel of the
-// window mapper.cpp:90 keeps.  FP32-VALU / gather-latency bound (<= 102 search steps x 3 bilinear samples), not HBM bound.
-// The per-keyframe relative poses come from k_age_table (never a per-pixel exp/log).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
+// One reference pixel of Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214).  The per-keyframe
+// relative poses come from k_age_table (never a per-pixel exp/log).  max_len >= 0: a pixel whose epipolar segment is longer than max_len pixels is not
+// searched here and the function returns false (the caller defers it); max_len < 0: no limit.  Returns true when the pixel is done.
+__device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const int seq, const int x, const int y, const float max_len)
 {
     const int w = a.w, h = a.h, npix = w * h;
-    // Only the window of mapper.cpp:90 (x in [16,144], y in [12,108]) is launched when the crop is on.
-    const int x_lo = a.crop ? 16 : 0, y_lo = a.crop ? 12 : 0;
-    const int ww = a.crop ? (min(144, w - 1) - 16 + 1) : w, wh = a.crop ? (min(108, h - 1) - 12 + 1) : h;
-    if (ww <= 0 || wh <= 0) return;
-    int seq, j;
-    if (!seq_pixel(ww * wh, seq, j)) return;
     const MonoSeq* m = a.meta ? a.meta + seq : nullptr;
-    if (m && a.ring_gray && m->need) return;          // this sequence created a keyframe instead (mapper.cpp:23-27)
-    const int wy = j / ww, wx = j - wy * ww;
-    const int x = x_lo + wx, y = y_lo + wy, i = y * w + x;
+    const int i = y * w + x;
     const size_t base = (size_t)seq * npix;
     const Pose rel_pose = m ? m->rel_pose : a.rel_pose;
     const float rel_tz = m ? m->rel_xi[2] : a.rel_tz;
@@ -210,12 +201,12 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     float pu, pv;
     warp(rel_pose, a.k, (float)x, (float)y, d, pu, pv);               // mapper.cpp:94
     int qx, qy;
-    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
-    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return true;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return true;
     const int age = (int)a.ref_age[base + i];                          // mapper.cpp:99
     int bi = n_hist - 1 - age;                                         // frame.hpp:176
     if (bi < 0 && a.clamp_age) bi = 0;
-    if (bi < 0 || bi >= n_hist) return;
+    if (bi < 0 || bi >= n_hist) return true;
     const AgeEntry& born = a.ages[(size_t)seq * a.R + bi];
     const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
     const float depth = d - rel_tz;                                    // mapper.cpp:104
@@ -229,6 +220,7 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
     const float sex = sx - ex, sey = sy - ey;
     const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
+    if (max_len >= 0.0f && length > max_len) return false;   // long search: deferred (never taken for NaN: the search then ends at once)
     // doMatching, implement.cpp:106-152
     const float og = a.obj_gray[base + qy * w + qx];
     const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
@@ -262,8 +254,8 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
         if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
         if (count++ > 100) break;
     }
-    if ((double)min_ssd > 3 * 0.1) return;                             // implement.cpp:145
-    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return;  // implement.cpp:196-200
+    if ((double)min_ssd > 3 * 0.1) return true;                             // implement.cpp:145
+    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return true;  // implement.cpp:196-200
     // depthEstimate, implement.cpp:49-71 (double from float inputs)
     float nd;
     {
@@ -300,7 +292,7 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
         mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
         my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
         const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
-        if (is_invalid(gx) || is_invalid(gy)) return;  // new_sigma = -1 fails the gate of mapper.cpp:122
+        if (is_invalid(gx) || is_invalid(gy)) return true;  // new_sigma = -1 fails the gate of mapper.cpp:122
         const float gl = fabsf(fmaf(gy, ly, gx * lx));
         const float gl2 = gl * gl, gp2 = gl / l;
         const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
@@ -315,6 +307,42 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
         a.ref_depth[base + i] = gd;                                    // mapper.cpp:130-131
         a.ref_sigma[base + i] = gs;
     }
+    return true;
+}
+
+// Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per reference pixel of the
+// window mapper.cpp:90 keeps.  FP32-VALU bound (<= 102 search steps x 3 bilinear samples per pixel), not HBM bound.
+// The search length varies per pixel by two orders of magnitude (it is the epipolar segment of depth +- sigma: a few pixels for most,
+// ~100 where depth - sigma clamps at 0.10 m) and a wave runs as long as its longest lane, so the search is split: the main pass
+// completes every pixel whose segment is at most DVO_UPDATE_SHORT pixels long and queues the others (per workgroup, in LDS); the
+// queued pixels -- a few per cent -- are then searched densely, one per lane.  Pixels are independent and the valid-update count is
+// an integer sum, so the order changes no result (bit-exact vs the one-pass form and the oracle: tests/test_gpu_parity.py).
+#define DVO_UPDATE_SHORT 3.0f
+__global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
+{
+    __shared__ int queue[256];
+    __shared__ int n_queued;
+    const int w = a.w, h = a.h;
+    // Only the window of mapper.cpp:90 (x in [16,144], y in [12,108]) is launched when the crop is on.
+    const int x_lo = a.crop ? 16 : 0, y_lo = a.crop ? 12 : 0;
+    const int ww = a.crop ? (min(144, w - 1) - 16 + 1) : w, wh = a.crop ? (min(108, h - 1) - 12 + 1) : h;
+    if (ww <= 0 || wh <= 0) return;
+    int seq, j;
+    const bool mine = seq_pixel(ww * wh, seq, j);       // (seq is block-uniform; only the last block of a sequence has idle threads)
+    if (a.meta && a.ring_gray && a.meta[seq].need) return;   // this sequence created a keyframe instead (mapper.cpp:23-27); block-uniform
+    if (threadIdx.x == 0) n_queued = 0;
+    __syncthreads();
+    if (mine) {
+        const int wy = j / ww, wx = j - wy * ww;
+        if (!depth_update_pixel(a, seq, x_lo + wx, y_lo + wy, DVO_UPDATE_SHORT)) queue[atomicAdd(&n_queued, 1)] = j;
+    }
+    __syncthreads();
+    const int nq = n_queued;
+    if ((int)threadIdx.x < nq) {
+        const int jq = queue[threadIdx.x];
+        const int wy = jq / ww, wx = jq - wy * ww;
+        (void)depth_update_pixel(a, seq, x_lo + wx, y_lo + wy, -1.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,24 +350,35 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
 // FrameHistory::push): its gray pyramid, the propagated top-level depth / sigma and the age map are copied over the reference
 // set's, and its top-level gray enters the keyframe ring (slot n_total % R).  One launch, every segment of every flagged sequence.
 // ------------------------------------------------------------------------------------------------
+#define DVO_PROMOTE_PER_THREAD 8
 __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
 {
     int total = a.npix;  // + the ring segment
     for (int g = 0; g < a.n_seg; g++) total += a.count[g];
-    int seq, i;
-    if (!seq_pixel(total, seq, i)) return;
+    // 2048 elements per workgroup: most sequences do not create a keyframe on a given frame, and a workgroup that only finds that
+    // out costs as much as one that copies -- fewer, fatter workgroups
+    const unsigned bps = ((unsigned)total + 256u * DVO_PROMOTE_PER_THREAD - 1u) / (256u * DVO_PROMOTE_PER_THREAD);
+    const int seq = (int)(blockIdx.x / bps);
     const MonoSeq& m = a.meta[seq];
     if (!a.all && !m.need) return;
-    for (int g = 0; g < a.n_seg; g++) {
-        if (i < a.count[g]) {
-            const size_t o = (size_t)seq * a.count[g] + i;
-            a.dst[g][o] = a.src[g][o];
-            return;
-        }
-        i -= a.count[g];
-    }
     const int slot = a.all ? 0 : m.n_total % a.R;   // (k_mono_commit increments n_total AFTER this kernel)
-    a.ring_gray[((size_t)seq * a.R + slot) * a.npix + i] = a.gray_top[(size_t)seq * a.npix + i];
+    const int i0 = (int)(blockIdx.x - (unsigned)seq * bps) * (256 * DVO_PROMOTE_PER_THREAD) + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < DVO_PROMOTE_PER_THREAD; k++) {
+        int i = i0 + k * 256;
+        if (i >= total) break;
+        bool done = false;
+        for (int g = 0; g < a.n_seg; g++) {
+            if (i < a.count[g]) {
+                const size_t o = (size_t)seq * a.count[g] + i;
+                a.dst[g][o] = a.src[g][o];
+                done = true;
+                break;
+            }
+            i -= a.count[g];
+        }
+        if (!done) a.ring_gray[((size_t)seq * a.R + slot) * a.npix + i] = a.gray_top[(size_t)seq * a.npix + i];
+    }
 }
 
 __global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src, float* __restrict__ dst, int count)
@@ -372,7 +411,7 @@ void launch_promote(const PromoteArgs& a, hipStream_t s)
 {
     int total = a.npix;
     for (int g = 0; g < a.n_seg; g++) total += a.count[g];
-    hipLaunchKernelGGL(k_promote, dim3(cdiv_u(total, 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_promote, dim3(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s)
