@@ -184,9 +184,11 @@ __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ de
 
 // ------------------------------------------------------------------------------------------------
 // One reference pixel of Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214).  The per-keyframe
-// relative poses come from k_age_table (never a per-pixel exp/log).  max_len >= 0: a pixel whose epipolar segment is longer than max_len pixels is not
-// searched here and the function returns false (the caller defers it); max_len < 0: no limit.  Returns true when the pixel is done.
-__device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const int seq, const int x, const int y, const float max_len)
+// relative poses come from k_age_table (never a per-pixel exp/log).
+// KEY_ONLY: stop after the epipolar segment is known and return the number of search steps the pixel will take (0 = the pixel
+// leaves before the search: nothing to do); otherwise run the pixel to the end (return value unused).
+template <bool KEY_ONLY>
+__device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int seq, const int x, const int y)
 {
     const int w = a.w, h = a.h, npix = w * h;
     const MonoSeq* m = a.meta ? a.meta + seq : nullptr;
@@ -201,12 +203,12 @@ __device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const in
     float pu, pv;
     warp(rel_pose, a.k, (float)x, (float)y, d, pu, pv);               // mapper.cpp:94
     int qx, qy;
-    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return true;
-    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return true;
+    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return 0;
+    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return 0;
     const int age = (int)a.ref_age[base + i];                          // mapper.cpp:99
     int bi = n_hist - 1 - age;                                         // frame.hpp:176
     if (bi < 0 && a.clamp_age) bi = 0;
-    if (bi < 0 || bi >= n_hist) return true;
+    if (bi < 0 || bi >= n_hist) return 0;
     const AgeEntry& born = a.ages[(size_t)seq * a.R + bi];
     const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
     const float depth = d - rel_tz;                                    // mapper.cpp:104
@@ -220,7 +222,10 @@ __device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const in
     warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
     const float sex = sx - ex, sey = sy - ey;
     const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
-    if (max_len >= 0.0f && length > max_len) return false;   // long search: deferred (never taken for NaN: the search then ends at once)
+    if constexpr (KEY_ONLY) {   // steps of the loop below: it runs while |pt - start| < length, pt advancing one pixel per step, at most 102 times
+        if (!(length > 0.0f)) return 1;                       // (NaN or zero length: the loop test fails at once; the pixel still has its tail)
+        return length >= 102.0f ? 103 : (int)length + 2;      // an upper bound within one step is all the ordering needs
+    }
     // doMatching, implement.cpp:106-152
     const float og = a.obj_gray[base + qy * w + qx];
     const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
@@ -254,8 +259,8 @@ __device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const in
         if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
         if (count++ > 100) break;
     }
-    if ((double)min_ssd > 3 * 0.1) return true;                             // implement.cpp:145
-    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return true;  // implement.cpp:196-200
+    if ((double)min_ssd > 3 * 0.1) return 0;                             // implement.cpp:145
+    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return 0;  // implement.cpp:196-200
     // depthEstimate, implement.cpp:49-71 (double from float inputs)
     float nd;
     {
@@ -292,7 +297,7 @@ __device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const in
         mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
         my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
         const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
-        if (is_invalid(gx) || is_invalid(gy)) return true;  // new_sigma = -1 fails the gate of mapper.cpp:122
+        if (is_invalid(gx) || is_invalid(gy)) return 0;  // new_sigma = -1 fails the gate of mapper.cpp:122
         const float gl = fabsf(fmaf(gy, ly, gx * lx));
         const float gl2 = gl * gl, gp2 = gl / l;
         const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
@@ -307,21 +312,23 @@ __device__ __forceinline__ bool depth_update_pixel(const UpdateArgs& a, const in
         a.ref_depth[base + i] = gd;                                    // mapper.cpp:130-131
         a.ref_sigma[base + i] = gs;
     }
-    return true;
+    return 0;
 }
 
 // Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per reference pixel of the
 // window mapper.cpp:90 keeps.  FP32-VALU bound (<= 102 search steps x 3 bilinear samples per pixel), not HBM bound.
 // The search length varies per pixel by two orders of magnitude (it is the epipolar segment of depth +- sigma: a few pixels for most,
-// ~100 where depth - sigma clamps at 0.10 m) and a wave runs as long as its longest lane, so the search is split: the main pass
-// completes every pixel whose segment is at most DVO_UPDATE_SHORT pixels long and queues the others (per workgroup, in LDS); the
-// queued pixels -- a few per cent -- are then searched densely, one per lane.  Pixels are independent and the valid-update count is
-// an integer sum, so the order changes no result (bit-exact vs the one-pass form and the oracle: tests/test_gpu_parity.py).
-#define DVO_UPDATE_SHORT 3.0f
+// ~100 where depth - sigma clamps at 0.10 m) and a wave runs as long as its longest lane.  So the workgroup first computes every
+// pixel's step count (the cheap head of the computation), sorts its 256 pixels by it (counting sort in LDS, longest first) and
+// hands them out in that order: each wave then holds pixels of similar length and finishes together.  Pixels that leave before
+// the search are dropped from the list.  Pixels are independent and the valid-update count is an integer sum, so the order changes
+// no result (bit-exact vs the oracle and the one-pass form: tests/test_gpu_parity.py, tests/test_real_data.py).
 __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
 {
-    __shared__ int queue[256];
-    __shared__ int n_queued;
+    __shared__ int bucket_cnt[128];     // pixels per step count, index 127 - steps (longest first)
+    __shared__ int bucket_off[128];
+    __shared__ int order[256];
+    __shared__ int n_listed;
     const int w = a.w, h = a.h;
     // Only the window of mapper.cpp:90 (x in [16,144], y in [12,108]) is launched when the crop is on.
     const int x_lo = a.crop ? 16 : 0, y_lo = a.crop ? 12 : 0;
@@ -330,18 +337,36 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     int seq, j;
     const bool mine = seq_pixel(ww * wh, seq, j);       // (seq is block-uniform; only the last block of a sequence has idle threads)
     if (a.meta && a.ring_gray && a.meta[seq].need) return;   // this sequence created a keyframe instead (mapper.cpp:23-27); block-uniform
-    if (threadIdx.x == 0) n_queued = 0;
+    if (threadIdx.x < 128) bucket_cnt[threadIdx.x] = 0;
     __syncthreads();
+    int steps = 0, rank = 0;
     if (mine) {
         const int wy = j / ww, wx = j - wy * ww;
-        if (!depth_update_pixel(a, seq, x_lo + wx, y_lo + wy, DVO_UPDATE_SHORT)) queue[atomicAdd(&n_queued, 1)] = j;
+        steps = depth_update_pixel<true>(a, seq, x_lo + wx, y_lo + wy);
+        if (steps > 0) rank = atomicAdd(&bucket_cnt[127 - steps], 1);
     }
     __syncthreads();
-    const int nq = n_queued;
-    if ((int)threadIdx.x < nq) {
-        const int jq = queue[threadIdx.x];
+    if (threadIdx.x < 64) {   // exclusive prefix sum over the 128 buckets, two per lane of wave 0
+        const int b0 = 2 * (int)threadIdx.x;
+        const int c0 = bucket_cnt[b0], c1 = bucket_cnt[b0 + 1];
+        int incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        const int excl = incl - (c0 + c1);
+        bucket_off[b0] = excl;
+        bucket_off[b0 + 1] = excl + c0;
+        if (threadIdx.x == 63) n_listed = incl;
+    }
+    __syncthreads();
+    if (steps > 0) order[bucket_off[127 - steps] + rank] = j;
+    __syncthreads();
+    if ((int)threadIdx.x < n_listed) {
+        const int jq = order[threadIdx.x];
         const int wy = jq / ww, wx = jq - wy * ww;
-        (void)depth_update_pixel(a, seq, x_lo + wx, y_lo + wy, -1.0f);
+        (void)depth_update_pixel<false>(a, seq, x_lo + wx, y_lo + wy);
     }
 }
 
