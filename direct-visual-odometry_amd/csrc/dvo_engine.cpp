@@ -502,6 +502,7 @@ int Keyframe::alloc(const Geometry& g, const dvo_config& cfg)
 // ------------------------------------------------------------------------------------------------ VisualOdometry
 VisualOdometry::~VisualOdometry()
 {
+    if (h_pin) (void)hipHostFree(h_pin);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -527,6 +528,7 @@ int VisualOdometry::init(const float K9[9], int width, int height, const dvo_con
     DVO_TRY(valid_dev.alloc(sizeof(int)));
     DVO_TRY(meta_dev.alloc(sizeof(MonoSeq)));
     DVO_HIP(hipMemset(meta_dev.p, 0, sizeof(MonoSeq)));
+    DVO_HIP(hipHostMalloc(&h_pin, sizeof(MonoSeq) + sizeof(dvo_track_log), hipHostMallocDefault));  // pinned: the per-frame read-back is one DMA
     memset(&h_meta, 0, sizeof h_meta);
     memset(&last_log, 0, sizeof last_log);
     return DVO_OK;
@@ -662,16 +664,16 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
     // Frame::updateXi (frame.cpp:7-14), Mapper::needNewFrame (mapper.cpp:45-60) and exp(xi) (system.hpp:73) on the device, by the
     // kernel the batched pipeline uses; the host keeps FrameHistory, so the reference keyframe's pose and id go up first.
-    struct { float ref_xi[6]; int ref_id; int n_total; } hdr;
+    MonoRef hdr;
     memcpy(hdr.ref_xi, ref.xi, sizeof hdr.ref_xi);
-    hdr.ref_id = ref.id; hdr.n_total = (int)hist.size();
-    static_assert(offsetof(MonoSeq, frame_xi) == 32, "MonoSeq starts with ref_xi, ref_id, n_total");
-    DVO_HIP(hipMemcpyAsync(meta_dev.p, &hdr, sizeof hdr, hipMemcpyHostToDevice, stream));
+    hdr.ref_id = ref.id; hdr.n_total = (int)hist.size(); hdr.valid = 1;
     launch_mono_decide(meta_dev.as<MonoSeq>(), trkM.state.as<SeqState>(), 1, frame.id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
-                       nullptr, nullptr, nullptr, stream);
-    DVO_HIP(hipMemcpyAsync(&h_meta, meta_dev.p, sizeof h_meta, hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipMemcpyAsync(&last_log, trkM.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
+                       nullptr, nullptr, nullptr, &hdr, stream);
+    DVO_HIP(hipMemcpyAsync(h_pin, meta_dev.p, sizeof(MonoSeq), hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipMemcpyAsync(reinterpret_cast<char*>(h_pin) + sizeof(MonoSeq), trkM.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
     DVO_HIP(hipStreamSynchronize(stream));
+    memcpy(&h_meta, h_pin, sizeof h_meta);
+    memcpy(&last_log, reinterpret_cast<char*>(h_pin) + sizeof(MonoSeq), sizeof last_log);
     memcpy(frame.rel_xi, h_meta.rel_xi, sizeof frame.rel_xi);
     memcpy(frame.xi, h_meta.frame_xi, sizeof frame.xi);
     frame.ref_id = ref.id;

@@ -156,6 +156,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     // so that a dvo_vo handle and a sequence of a mono dvo_batch produce identical bits.
     DevBuf meta_dev, hist_xi_dev, gray_tab_dev;
     MonoSeq h_meta;
+    void* h_pin = nullptr;   // pinned staging for the per-frame read-back (MonoSeq + track log)
     std::vector<float> init_depth, init_sigma;
     int latest_id = -1;                                // Frame::latest_id, frame.cpp:5
     int history_limit = 0;                             // 0 = keep every keyframe (the reference); N = keep the newest N

@@ -217,8 +217,9 @@ struct PromoteArgs {   // a tracked frame becomes the newest keyframe of the seq
     int all;                 // 1: every sequence (first frame), 0: need flag
 };
 
+struct MonoRef { float ref_xi[6]; int ref_id, n_total, valid; };   // reference keyframe of a single dvo_vo handle (kernel argument)
 void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
-                        float* xi_world, float* T_world, int* is_key, hipStream_t s);
+                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s);
 void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,
                         hipStream_t s);
 void launch_age_table(const AgeTableArgs& a, hipStream_t s);

@@ -28,11 +28,15 @@ __device__ __forceinline__ bool seq_pixel(int npix, int& seq, int& i)
 // rel_pose <- exp(+rel_xi), T_world <- exp(frame_xi).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation,
-                                                    int max_frames, float* xi_world, float* T_world, int* is_key)
+                                                    int max_frames, float* xi_world, float* T_world, int* is_key, MonoRef host_ref)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n_seq) return;
     MonoSeq& m = meta[s];
+    if (host_ref.valid) {   // a dvo_vo handle keeps FrameHistory on the host: the reference keyframe's pose / id arrive as kernel arguments
+        for (int i = 0; i < 6; i++) m.ref_xi[i] = host_ref.ref_xi[i];
+        m.ref_id = host_ref.ref_id; m.n_total = host_ref.n_total;
+    }
     float rel[6], ref[6], fx[6];
     for (int i = 0; i < 6; i++) { rel[i] = state[s].xi[i]; ref[i] = m.ref_xi[i]; }
     se3_concatenate_f(ref, rel, fx);
@@ -415,10 +419,12 @@ __global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
 void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
-                        float* xi_world, float* T_world, int* is_key, hipStream_t s)
+                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s)
 {
+    MonoRef r;
+    if (host_ref) r = *host_ref; else { for (int i = 0; i < 6; i++) r.ref_xi[i] = 0.0f; r.ref_id = 0; r.n_total = 0; r.valid = 0; }
     hipLaunchKernelGGL(k_mono_decide, dim3(cdiv_u(n_seq, 64)), dim3(64), 0, s, meta, state, n_seq, frame_id, min_translation, max_frames,
-                       xi_world, T_world, is_key);
+                       xi_world, T_world, is_key, r);
 }
 
 void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,

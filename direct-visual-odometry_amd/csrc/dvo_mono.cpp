@@ -100,7 +100,7 @@ int MonoBatch::odometrize(const FrameInput& in)
     build_pyramid(frm, gin, stream);                                           // Frame(gray, K, 3, 2)
     DVO_TRY(trk.track(frm, ref, stream));                                      // system.hpp:57
     launch_mono_decide(m, trk.state.as<SeqState>(), n_seq, frame_id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
-                       xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), stream);
+                       xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), nullptr, stream);
     // ---- Mapper::estimate (mapper.cpp:16-33), both branches launched, each sequence takes its own ----
     {   // need: propagate the reference maps into the frame (mapper.cpp:62-74) ...
         PropArgs a;
