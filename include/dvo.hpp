@@ -127,6 +127,11 @@ public:
     BatchTracker& operator=(const BatchTracker&) = delete;
     void pushDevice(const float* gray, const float* depth, const float* sigma) { check(dvo_batch_push_device(b_, gray, depth, sigma)); }
     void pushHost(const float* gray, const float* depth, const float* sigma) { check(dvo_batch_push_host(b_, gray, depth, sigma)); }
+    // raw sensor frames as cv::imread delivers them (u8 gray / RGB(A), u16 depth): converted inside the pyramid kernel
+    void pushRawDevice(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale = 0.0f)
+    { check(dvo_batch_push_raw_device(b_, rgb, channels, depth16, depth_scale)); }
+    void pushRawHost(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale = 0.0f)
+    { check(dvo_batch_push_raw_host(b_, rgb, channels, depth16, depth_scale)); }
     std::vector<Vec6> lastTwists()
     {
         std::vector<Vec6> out(n_);
@@ -137,6 +142,34 @@ public:
     {
         std::vector<Mat4> out(n_);
         check(dvo_batch_last_poses(b_, nullptr, out[0].data()));
+        return out;
+    }
+    dvo_batch* handle() { return b_; }
+
+private:
+    dvo_batch* b_ = nullptr;
+    int n_;
+};
+
+// n_seq independent MONO sequences on one GPU: System::VisualOdometry::odometrize (system.hpp:44-74: track + Mapper::estimate +
+// regularize) for every sequence per call; Mapper::needNewFrame (src/map/mapper.cpp:45-60) is decided per sequence on the device
+class BatchMono {
+public:
+    BatchMono(int n_seq, const Mat3& K, int width, int height, int ring_keyframes = 8, const dvo_config* cfg = nullptr) : n_(n_seq)
+    {
+        check(dvo_batch_create_mono(n_seq, K.data(), width, height, ring_keyframes, cfg, &b_));
+    }
+    ~BatchMono() { dvo_batch_destroy(b_); }
+    BatchMono(const BatchMono&) = delete;
+    BatchMono& operator=(const BatchMono&) = delete;
+    void setInitialDepth(const float* depth, const float* sigma) { check(dvo_batch_set_initial_depth(b_, depth, sigma)); }
+    void odometrizeDevice(const float* gray) { check(dvo_batch_odometrize_device(b_, gray)); }
+    void odometrizeRawDevice(const uint8_t* rgb, int channels) { check(dvo_batch_odometrize_raw_device(b_, rgb, channels)); }
+    std::vector<Mat4> worldPoses(std::vector<int>* is_keyframe = nullptr)
+    {
+        std::vector<Mat4> out(n_);
+        if (is_keyframe) is_keyframe->resize(n_);
+        check(dvo_batch_world_poses(b_, nullptr, out[0].data(), is_keyframe ? is_keyframe->data() : nullptr));
         return out;
     }
     dvo_batch* handle() { return b_; }

@@ -10,3 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python
 cp /tmp/prof_$TAG/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv && cp /tmp/prof_$TAG.json $R/gpurun_out/${TAG}_bench_under_rocprof.json && echo "stats done" &&
 bash $R/tools/pmc_gn.sh 0.5 4 2 64 > /dev/null 2>&1; cp /tmp/pmc_all.txt $R/gpurun_out/${TAG}_k_track_gn_pmc.txt && echo "pmc done" &&
 bash $R/tools/pmc_traffic.sh > /dev/null 2>&1; cp $R/gpurun_out/traffic.json $R/gpurun_out/${TAG}_traffic.json && echo "traffic done"
+# launch schedule of the default bench (per-position kernel times of one step)
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$TAG -- python3 $R/bench.py --no-cpu-baseline --pcie-steps 0 --no-roofline --no-secondary --steps 8 > /dev/null 2>&1 &&
+python3 $R/tools/trace_schedule.py "/tmp/tr_$TAG/*/*kernel_trace.csv" 60 > $R/gpurun_out/${TAG}_launch_schedule.txt && echo "schedule done"

@@ -21,7 +21,7 @@ def main():
     # keep whole steps only: a step starts at k_pyramid
     steps, cur = [], None
     for s, e, n in rows:
-        if "k_pyramid" in n:
+        if "k_pyramid" in n and ("raw4" in n or "k_pyramid(" in n):
             if cur: steps.append(cur)
             cur = []
         if cur is not None:
