@@ -260,14 +260,8 @@ int dvo_batch_push_raw_host(dvo_batch* b, const uint8_t* rgb, int channels, cons
     FrameInput in;
     DVO_TRY(raw_input(b, rgb, channels, depth16, depth_scale, in));
     Batch& B = b->impl;
-    DVO_TRY(select_device(B.device));
     const size_t px = (size_t)B.n_seq * B.g.src_w * B.g.src_h;
-    if (B.in_rgb.bytes < px * (size_t)channels) DVO_TRY(B.in_rgb.alloc(px * (size_t)channels));
-    if (B.in_d16.bytes < px * 2) DVO_TRY(B.in_d16.alloc(px * 2));
-    DVO_HIP(hipMemcpyAsync(B.in_rgb.p, rgb, px * (size_t)channels, hipMemcpyHostToDevice, B.stream));
-    DVO_HIP(hipMemcpyAsync(B.in_d16.p, depth16, px * 2, hipMemcpyHostToDevice, B.stream));
-    in.rgb = B.in_rgb.as<uint8_t>(); in.depth16 = B.in_d16.as<uint16_t>();
-    return B.push(in);
+    return B.push_host_frame(rgb, px * (size_t)channels, depth16, px * 2, nullptr, 0, in);
 }
 
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma)
@@ -275,15 +269,10 @@ int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, con
     if (!b || !gray || !depth || !sigma) return DVO_ERR_BAD_ARGUMENT;
     DVO_NOT_MONO(b);
     Batch& B = b->impl;
-    DVO_TRY(select_device(B.device));
     const size_t n = (size_t)B.n_seq * B.g.src_w * B.g.src_h * sizeof(float);
-    if (B.in_gray.bytes < n) { DVO_TRY(B.in_gray.alloc(n)); DVO_TRY(B.in_depth.alloc(n)); DVO_TRY(B.in_sigma.alloc(n)); }
-    DVO_HIP(hipMemcpyAsync(B.in_gray.p, gray, n, hipMemcpyHostToDevice, B.stream));
-    DVO_HIP(hipMemcpyAsync(B.in_depth.p, depth, n, hipMemcpyHostToDevice, B.stream));
-    DVO_HIP(hipMemcpyAsync(B.in_sigma.p, sigma, n, hipMemcpyHostToDevice, B.stream));
     FrameInput in;
-    in.gray = B.in_gray.as<float>(); in.depth = B.in_depth.as<float>(); in.sigma = B.in_sigma.as<float>();
-    return B.push(in);
+    in.gray = gray; in.depth = depth; in.sigma = sigma;   // (replaced by the staging pointers)
+    return B.push_host_frame(gray, n, depth, n, sigma, n, in);
 }
 
 int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel)

@@ -759,6 +759,11 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* r
 Batch::~Batch()
 {
     if (pstream) { (void)hipStreamSynchronize(pstream); (void)hipStreamDestroy(pstream); }
+    if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
+    for (auto& st : stage) {
+        if (st.copied) (void)hipEventDestroy(st.copied);
+        if (st.consumed) (void)hipEventDestroy(st.consumed);
+    }
     if (ev_last_track) (void)hipEventDestroy(ev_last_track);
     for (int i = 0; i < 3; i++) if (ev_built[i]) (void)hipEventDestroy(ev_built[i]);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -788,6 +793,41 @@ int Batch::init(int n, const float K9[9], int w, int h, int levels, int culls, c
 // Builds the pyramids of a frame that will be handed to push_device later (call order per step: prefetch(k+1); push(k)) on the
 // side stream.  The set it builds into may be the reference of the tracking queued last: the build waits for that tracking --
 // not for anything queued afterwards -- and then runs beside the tracking of frame k.
+// One frame of every sequence from HOST memory: up to three buffers (float gray / depth / sigma, or raw rgb / depth16) go to the
+// staging slot of this push on the copy stream; the tracking stream waits for that copy only.  Slot k & 1 is reused by push k + 2,
+// whose copy waits until push k (pyramid build + tracking) is done with it.
+int Batch::push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2, FrameInput in)
+{
+    DVO_TRY(select_device(device));
+    if (!cstream) {
+        DVO_HIP(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        for (auto& st : stage) {
+            DVO_HIP(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+            DVO_HIP(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+        }
+    }
+    // The adaptive schedule keeps the host inside track() until the GPU is nearly done with the frame; a host-fed batch wants the
+    // next frame's transfer queued meanwhile, so it runs the fixed schedule (bit-identical results, tested).
+    trk.adaptive = false;
+    Stage& st = stage[n_host_push & 1];
+    n_host_push++;
+    if (st.a.bytes < n0) DVO_TRY(st.a.alloc(n0));
+    if (p1 && st.b.bytes < n1) DVO_TRY(st.b.alloc(n1));
+    if (p2 && st.c.bytes < n2) DVO_TRY(st.c.alloc(n2));
+    if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
+    DVO_HIP(hipMemcpyAsync(st.a.p, p0, n0, hipMemcpyHostToDevice, cstream));
+    if (p1) DVO_HIP(hipMemcpyAsync(st.b.p, p1, n1, hipMemcpyHostToDevice, cstream));
+    if (p2) DVO_HIP(hipMemcpyAsync(st.c.p, p2, n2, hipMemcpyHostToDevice, cstream));
+    DVO_HIP(hipEventRecord(st.copied, cstream));
+    DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));
+    if (in.raw()) { in.rgb = st.a.as<uint8_t>(); in.depth16 = st.b.as<uint16_t>(); }
+    else { in.gray = st.a.as<float>(); in.depth = st.b.as<float>(); in.sigma = st.c.as<float>(); }
+    const int rc = push(in);
+    DVO_HIP(hipEventRecord(st.consumed, stream));
+    st.used = true;
+    return rc;
+}
+
 int Batch::prefetch(const FrameInput& in)
 {
     if (!in.key0() || !in.has_depth()) { set_error("null device pointer"); return DVO_ERR_BAD_ARGUMENT; }

@@ -198,8 +198,12 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
     hipEvent_t ev_last_track = nullptr, ev_built[3] = {nullptr, nullptr, nullptr};
     bool tracked_once = false;
     bool have_poses = false;
-    DevBuf in_gray, in_depth, in_sigma;  // staging for push_host
-    DevBuf in_rgb, in_d16;               // staging for push_raw_host
+    // Host input (push_host / push_raw_host): two staging slots filled on a copy stream, so the H2D transfer of frame k+1 runs
+    // beside the tracking of frame k (PCIe is the bound of a host-fed batch: 0.92 MB per raw 640x480 frame).
+    struct Stage { DevBuf a, b, c; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; } stage[2];
+    hipStream_t cstream = nullptr;
+    int n_host_push = 0;
+    int push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2, FrameInput in);
     ~Batch();
     int init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c);
     int free_slot() const  // a frame set that is neither the reference nor waiting prefetched (-1: none)
