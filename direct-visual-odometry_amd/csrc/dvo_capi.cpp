@@ -40,6 +40,7 @@ void dvo_config_default(dvo_config* c)
     c->track_streams = 0;
     c->track_adaptive = 0;
     c->track_fused_tiles = 0;
+    c->track_single_launch = 0;
 }
 
 const char* dvo_version(void) { return "dvo-mi355x 0.1 (gfx950)"; }

@@ -301,6 +301,18 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         memset(h_progress, 0, words * sizeof(int));
         DVO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_progress), h_progress, 0));
     }
+    // one launch per iteration (k_track_gn_fused) for handles of a few sequences, per level: the kernel carries the solve's 248
+    // VGPRs (two waves per SIMD), so only where the level's grid is a few dozen workgroups -- measured on one 640x480 stream:
+    // 14-16 us per iteration against 17-18 us for the launch pair up to 52 workgroups, but 31 us against 18 us at 300
+    for (int l = 0; l < g.levels; l++) {
+        const GnTiling tl = gn_tiling(g.w[l], g.h[l], ppt[l], level_params(l).crop);
+        single_launch[l] = cfg.track_single_launch >= 0 && n_seq <= 8 && tile_margin == 0 && !fused[l] && !cfg.profile && n_sub == 1 &&
+                           gn_fused_available(ppt[l], group[l]) && tl.live_count > 0 && (long long)n_seq * tl.live_count <= 64;
+    }
+    DVO_TRY(ticket.alloc(sizeof(int) * (size_t)n_seq));
+    DVO_HIP(hipMemset(ticket.p, 0, ticket.bytes));
+    DVO_TRY(freport.alloc(sizeof(int) * 2 * 2 * (size_t)DVO_MAX_LEVELS * DVO_MAX_ITERATIONS));
+    DVO_HIP(hipMemset(freport.p, 0, freport.bytes));
     DVO_TRY(xi_out.alloc(sizeof(float) * 6 * (size_t)n_seq));
     DVO_TRY(T_out.alloc(sizeof(float) * 16 * (size_t)n_seq));
     DVO_HIP(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
@@ -371,8 +383,12 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         prog_h = h_progress + off; prog_d = d_progress + off;
         for (int i = 0; i < DVO_MAX_LEVELS * DVO_MAX_ITERATIONS; i++) prog_h[i] = 0;
     }
+    bool any_single = false;
+    for (int l = 0; l < g.levels; l++) any_single = any_single || single_launch[l];
+    int* rep_set = freport.as<int>() + (size_t)(progress_set & 1) * 2 * DVO_MAX_LEVELS * DVO_MAX_ITERATIONS;
+    if (any_single) DVO_HIP(hipMemsetAsync(rep_set, 0, sizeof(int) * 2 * DVO_MAX_LEVELS * DVO_MAX_ITERATIONS, s));
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
-        const bool lists = tile_margin == 0;  // (k_track_gn_tile keeps the per-sequence active flag test)
+        const bool lists = tile_margin == 0 && !single_launch[level];  // (k_track_gn_tile keeps the per-sequence active flag test)
         const size_t level_px = (size_t)g.w[level] * g.h[level];
         const int host_its = fused[level] ? 1 : max_it;  // a fused level iterates on the device (k_track_level)
         for (int it = 0; it < host_its; it++) {        // tracker.cpp:42
@@ -404,6 +420,21 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 ga.ref_iz += q0 * level_px; ga.ref_wgt += q0 * level_px;
                 ga.state += q0;
                 ga.partials += (size_t)q0 * nblk[level] * 32;
+                if (single_launch[level]) {   // GN accumulation + solve of this iteration in one launch (k_track_gn_fused)
+                    SolveArgs fa;
+                    fa.state = state.as<SeqState>() + q0;
+                    fa.partials = ga.partials;
+                    fa.log = log.as<dvo_track_log>() + q0;
+                    fa.result = nullptr;
+                    fa.counters = nullptr;
+                    fa.nblk = nblk[level]; fa.level = level; fa.level_pixels = (int)level_px;
+                    fa.max_iterations = cfg.max_iterations; fa.fixed_iterations = cfg.fixed_iterations;
+                    fa.min_update = cfg.min_update; fa.min_residual = cfg.min_residual;
+                    fa.ignore_active = first;
+                    if (launch_track_gn_fused(ga, fa, nq, ppt[level], group[level], ticket.as<int>(), rep_set + 2 * (level * DVO_MAX_ITERATIONS + it),
+                                              adaptive ? prog_d + level * DVO_MAX_ITERATIONS + it : nullptr, sk))
+                        continue;
+                }
                 if (fused[level]) {
                     SolveArgs fa;
                     fa.state = state.as<SeqState>() + q0;

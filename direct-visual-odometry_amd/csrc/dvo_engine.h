@@ -106,6 +106,8 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     int ppt[DVO_MAX_LEVELS], nblk[DVO_MAX_LEVELS], group[DVO_MAX_LEVELS];
     int tiles_x[DVO_MAX_LEVELS], tiles_y[DVO_MAX_LEVELS];
     bool fused[DVO_MAX_LEVELS];  // level runs as ONE k_track_level launch (all iterations on the device)
+    bool single_launch[DVO_MAX_LEVELS];  // level runs one k_track_gn_fused launch per iteration (small handles: see dvo_kernels.hip)
+    DevBuf ticket, freport;      // k_track_gn_fused: arrival tickets [n_seq]; (reported, active) per (set, level, iteration)
     // Adaptive schedule: progress words in mapped host memory, one per (level, iteration), two sets used alternately.
     // k_gn_solve's workgroup 0 stores (active sequences + 1); the host reads them to stay ~2 iterations ahead of the GPU and
     // to stop enqueuing a level once a launch reported zero active sequences (its remaining launches would be empty).

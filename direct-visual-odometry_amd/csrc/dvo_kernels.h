@@ -243,6 +243,10 @@ inline void gn_tile_geometry(int w, int h, int ppt, int& tiles_x, int& tiles_y)
     tiles_y = (h + 4 * ppt - 1) / (4 * ppt);
 }
 void launch_gn_solve(const SolveArgs& a, int n_seq, hipStream_t s);
+// one Tracker::track iteration in one launch for a few sequences (k_track_gn_fused); false = no instance for (ppt, group)
+bool launch_track_gn_fused(const GnArgs& a, const SolveArgs& sa, int n_seq, int ppt, int group, int* ticket, int* report, int* progress,
+                           hipStream_t s);
+inline bool gn_fused_available(int ppt, int group) { return (ppt == 1 && group == 1) || (ppt == 2 && group == 2) || (ppt == 4 && group == 2); }
 // k_track_level: every iteration of one level in one launch (one workgroup per sequence); the level must have been
 // tiled with 4 pixels per thread (ga.nblk = gn_blocks_per_seq(w, h, 4)) and have at most DVO_FUSED_MAX_TILES tiles
 #define DVO_FUSED_MAX_TILES 8

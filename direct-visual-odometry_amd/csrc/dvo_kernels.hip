@@ -792,6 +792,34 @@ __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, S
 // waiting out a full chain.  Stage one: team t (32 lanes = the 32 columns of a partial row) sums the rows of sequence t.
 #define DVO_SOLVE_SEQ 8
 #define DVO_SOLVE_GROUPS 4   /* row classes of the fixed summation order: rows b = g (mod 4) in batches of 8, then (s0+s1)+(s2+s3) */
+// Second reduction stage for one column of one sequence: the workgroup partials p[b * 32], b = 0 .. nblk-1, summed in double in a
+// FIXED order -- four row classes (b mod 4), 32 rows per batch with all 32 loads in flight, then (s0 + s1) + (s2 + s3) -- shared by
+// k_gn_solve, k_track_gn_fused and (re-stated on LDS rows) k_track_level, so every schedule gives the same bits.
+// Rows outside [blk_first, blk_first + blk_count) were not written (crop window): they count as exact zeros in the same slots.
+__device__ __forceinline__ double sum_partial_rows(const float* p, const int nblk, const int blk_first, const int blk_count)
+{
+    const int live0 = blk_count < 0 ? 0 : blk_first, live1 = blk_count < 0 ? nblk : blk_first + blk_count;
+    double sg[DVO_SOLVE_GROUPS] = {0.0, 0.0, 0.0, 0.0};
+    for (int b0 = 0; b0 < nblk; b0 += 8 * DVO_SOLVE_GROUPS) {  // 32 loads in flight per lane
+        float v[DVO_SOLVE_GROUPS][8];
+#pragma unroll
+        for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int b = b0 + g + DVO_SOLVE_GROUPS * j;
+                const bool live = (b >= live0) & (b < live1);
+                const float x = p[(size_t)(live ? b : 0) * 32];  // (always a valid address: no branch around the load)
+                v[g][j] = live ? x : 0.0f;
+            }
+#pragma unroll
+        for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (b0 + g < nblk) sg[g] += (double)v[g][j];  // (a class with no row left adds nothing, as before)
+    }
+    return (sg[0] + sg[1]) + (sg[2] + sg[3]);
+}
+
 __global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
 {
     __shared__ double tot[DVO_SOLVE_SEQ][32];
@@ -825,29 +853,7 @@ __global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
     const int t_slot = (int)blockIdx.x * DVO_SOLVE_SEQ + team;
     if (t_slot < n_in && c < 29) {
         const int t_seq = a.list_in ? a.list_in[4 + t_slot] : t_slot;
-        const float* p = a.partials + (size_t)t_seq * a.nblk * 32 + c;
-        // rows outside the live range were not written by k_track_gn (crop window): they count as exact zeros, in the
-        // same summation slots, so the result is bit-identical to summing stored zeros
-        const int live0 = a.blk_count < 0 ? 0 : a.blk_first, live1 = a.blk_count < 0 ? a.nblk : a.blk_first + a.blk_count;
-        double sg[DVO_SOLVE_GROUPS] = {0.0, 0.0, 0.0, 0.0};
-        for (int b0 = 0; b0 < a.nblk; b0 += 8 * DVO_SOLVE_GROUPS) {  // 32 loads in flight per lane
-            float v[DVO_SOLVE_GROUPS][8];
-#pragma unroll
-            for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int b = b0 + g + DVO_SOLVE_GROUPS * j;
-                    const bool live = (b >= live0) & (b < live1);
-                    const float x = p[(size_t)(live ? b : 0) * 32];  // (always a valid address: no branch around the load)
-                    v[g][j] = live ? x : 0.0f;
-                }
-#pragma unroll
-            for (int g = 0; g < DVO_SOLVE_GROUPS; g++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if (b0 + g < a.nblk) sg[g] += (double)v[g][j];  // (a class with no row left adds nothing, as before)
-        }
-        tot[team][c] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+        tot[team][c] = sum_partial_rows(a.partials + (size_t)t_seq * a.nblk * 32 + c, a.nblk, a.blk_first, a.blk_count);
     } else if (c >= 29) {
         tot[team][c] = 0.0;
     }
@@ -918,6 +924,81 @@ __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, S
         atomicAdd(&a.counters[1], 1ull);
     }
     return active | (updated ? 2 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_track_gn_fused: one Tracker::track iteration in ONE launch, for a handful of sequences (a dvo_vo handle: one).  Every
+// workgroup evaluates its tile exactly as k_track_gn does; the workgroup that finishes a sequence's LAST tile (an arrival ticket
+// per sequence) then runs what k_gn_solve would: the second reduction stage in the same fixed order and solve_finish().  With one
+// sequence the two-kernel form is nothing but latency -- two launches, two kernel boundaries and a cold-cache solve kernel per
+// iteration; here it is one launch and the solve starts the moment the last partial row lands.  The price is the solve's register
+// footprint (248 VGPRs, two waves per SIMD) for the whole kernel, which is irrelevant for the <= 1024 workgroups this path is used
+// for and ruinous for a batch (measured in round 1): the host picks it per level (Tracker::track).
+// Hand-off: partial rows are plain stores; each workgroup drains them (vmcnt(0)), barrier, lane 0 agent-scope release fence, then the
+// ticket (agent-scope atomic add); the last arriver takes an agent-scope acquire fence (invalidates this CU's L1) before anyone
+// in its workgroup loads the rows.  No workgroup ever waits for another one: nothing can hang.
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+    int* ticket;        // [n_seq] arrival counters, zero between launches
+    int* report;        // 2 ints of THIS (level, iteration): [0] sequences reported, [1] sequences still active afterwards
+    int* progress;      // optional, fine-grained HOST memory: last reporter stores (active afterwards + 1)
+    int n_seq;
+};
+
+template <int PPT, int G, bool T2D>
+__global__ void __launch_bounds__(256) k_track_gn_fused(GnArgs a, SolveArgs sa, FusedArgs f)
+{
+    __shared__ GnTileLds<PPT> lds;
+    __shared__ double tot[32];
+    __shared__ int last_s;
+    const int tile_id = (int)blockIdx.x;                       // grid = n_seq * blk_count exactly
+    const int seq = tile_id / a.blk_count, blk = a.blk_first + (tile_id - seq * a.blk_count);
+    SeqState& st = sa.state[seq];
+    auto report = [&](int active) {                              // one thread per sequence and launch
+        if (active) __hip_atomic_fetch_add(&f.report[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int r = __hip_atomic_fetch_add(&f.report[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == f.n_seq - 1 && f.progress) {
+            const int act = __hip_atomic_load(&f.report[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f.progress, act + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    if (!sa.ignore_active && st.active == 0) {                   // converged sequence: its first tile reports, nobody works
+        if (blk == a.blk_first && threadIdx.x == 0) report(0);
+        return;
+    }
+    const Pose pose = st.pose;                                   // wave-uniform -> scalar loads
+    gn_tile<PPT, G, false, T2D>(a, pose, seq, blk, lds, a.partials + ((size_t)seq * a.nblk + blk) * 32);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's row stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&f.ticket[seq], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == a.blk_count - 1) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&f.ticket[seq], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        tot[c] = c < 29 ? sum_partial_rows(a.partials + (size_t)seq * a.nblk * 32 + c, a.nblk, sa.blk_first, sa.blk_count) : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float xi[6];
+    double Tc[12];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xi[i] = st.xi[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Tc[i] = st.Tc[i];
+    Pose np;
+    const int r = solve_finish(sa, seq, st, tot, sa.ignore_active, st.iter, xi, Tc, np);
+    report(r & 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1287,6 +1368,31 @@ void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_
         case 82: launch_track_gn_t<8, 2>(a, grid, s); break;
         default: launch_track_gn_t<8, 4>(a, grid, s); break;
     }
+}
+
+// k_track_gn_fused for the (ppt, group) pairs the small-batch tiling picks; returns false when there is no such instance
+bool launch_track_gn_fused(const GnArgs& a0, const SolveArgs& sa0, int n_seq, int ppt, int group, int* ticket, int* report, int* progress,
+                           hipStream_t s)
+{
+    GnArgs a = a0;
+    SolveArgs sa = sa0;
+    a.n_seq = n_seq; a.list = nullptr; a.next_count = nullptr; a.mask = nullptr;
+    const GnTiling tl = gn_tiling(a.w, a.h, ppt, a.prm.crop);
+    a.blk_first = tl.live_first; a.blk_count = tl.live_count;
+    a.t_shift = tl.shift; a.x_org = tl.x_org; a.y_org = tl.y_org;
+    if (tl.t2d) a.tiles_x = tl.tiles_x;
+    sa.n_seq = n_seq; sa.list_in = nullptr; sa.list_out = nullptr; sa.progress = nullptr;
+    sa.blk_first = tl.live_first; sa.blk_count = tl.live_count;
+    if (a.blk_count <= 0) return false;
+    FusedArgs f{ticket, report, progress, n_seq};
+    const dim3 grid((unsigned)a.blk_count * (unsigned)n_seq);
+    const int key = ppt * 10 + group;
+    if (key == 11) hipLaunchKernelGGL((k_track_gn_fused<1, 1, false>), grid, dim3(256), 0, s, a, sa, f);
+    else if (key == 22) hipLaunchKernelGGL((k_track_gn_fused<2, 2, false>), grid, dim3(256), 0, s, a, sa, f);
+    else if (key == 42 && tl.t2d) hipLaunchKernelGGL((k_track_gn_fused<4, 2, true>), grid, dim3(256), 0, s, a, sa, f);
+    else if (key == 42) hipLaunchKernelGGL((k_track_gn_fused<4, 2, false>), grid, dim3(256), 0, s, a, sa, f);
+    else return false;
+    return true;
 }
 
 void launch_track_level(const GnArgs& ga0, const SolveArgs& sa0, int n_seq, hipStream_t s)

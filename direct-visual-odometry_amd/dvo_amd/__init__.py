@@ -29,7 +29,8 @@ class Config(C.Structure):
                 ("sigma_max", C.c_float), ("min_depth", C.c_float), ("keyframe_min_translation", C.c_float),
                 ("keyframe_max_frames", C.c_int), ("rng_seed", C.c_uint32), ("device", C.c_int),
                 ("stream", C.c_void_p), ("profile", C.c_int), ("gn_pixels_per_thread", C.c_int),
-                ("gn_use_lds_patch", C.c_int), ("gn_gather_group", C.c_int), ("track_streams", C.c_int), ("track_adaptive", C.c_int), ("track_fused_tiles", C.c_int)]
+                ("gn_use_lds_patch", C.c_int), ("gn_gather_group", C.c_int), ("track_streams", C.c_int), ("track_adaptive", C.c_int), ("track_fused_tiles", C.c_int),
+                ("track_single_launch", C.c_int)]
 
 
 class TrackLog(C.Structure):
