@@ -72,6 +72,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "kinect50mm_excerpt.npz"), depth16=d, rgba=c)
     print("kinect: depth", d.shape, d.dtype, "zeros %.3f" % (d == 0).mean(), "rgba", c.shape)
 
+    # ---- KINECT_50MM as a sensor-depth sequence: the IR image is registered with the depth image (same sensor), so four
+    #      (ir, depth) pairs are a real RGB-D-like input with real holes and noise for the odometrizeUsingDepth path ----
+    irs, deps = [], []
+    for k in (1, 2, 3, 4):
+        ir = dvo.imread(os.path.join(REF, "KINECT_50MM", "ir%02d.png" % k))      # [424, 512] u16
+        dd = dvo.imread(os.path.join(REF, "KINECT_50MM", "depth%02d.png" % k))
+        irs.append(np.minimum(ir[::2, ::2] >> 5, 255).astype(np.uint8))           # 256 x 212 u8 gray
+        deps.append(dd[::2, ::2].copy())
+    np.savez_compressed(os.path.join(HERE, "kinect50mm_ir_depth.npz"), gray_u8=np.stack(irs), depth16=np.stack(deps))
+    print("kinect ir/depth sequence:", np.stack(irs).shape, "holes %.3f" % (np.stack(deps) == 0).mean())
+
 
 if __name__ == "__main__":
     main()

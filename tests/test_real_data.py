@@ -217,3 +217,77 @@ def test_undistort_kernel_on_a_real_frame():
     exp = exp.copy(); exp[inv] = np.float32(-2.0)
     assert ((got <= -2.0) != inv).mean() < 1e-3
     assert (got == exp).mean() > 0.999
+
+
+# ---------------------------------------------------------------- the sensor-depth path on real Kinect frames
+K_KINECT_IR = np.array([[365.0, 0, 256.0], [0, 365.0, 212.0], [0, 0, 1]], np.float32)   # nominal Kinect v2 depth / IR intrinsics (512 x 424)
+
+
+def _kinect_sequence():
+    """Four (IR, depth) pairs of data/KINECT_50MM as raw sensor frames at 512 x 424 (the stored 256 x 212 excerpt, every pixel
+    repeated 2 x 2, decimates back to exactly the stored pixels in Frame(g, d, s, K, 4, 1)) and as the float maps the loader makes."""
+    fx = np.load(os.path.join(GOLD, "kinect50mm_ir_depth.npz"))
+    g8 = np.repeat(np.repeat(fx["gray_u8"], 2, axis=1), 2, axis=2)
+    d16 = np.repeat(np.repeat(fx["depth16"], 2, axis=1), 2, axis=2)
+    fl = [ingest_np(g8[i], d16[i]) for i in range(g8.shape[0])]
+    return g8, d16, fl
+
+
+def test_kinect_sequence_fixture_has_real_holes():
+    g8, d16, fl = _kinect_sequence()
+    assert g8.shape == (4, 424, 512) and 0.03 < (d16 == 0).mean() < 0.2
+    g, d, s = fl[0]
+    assert (g[d16[0] == 0] == -2.0).all() and (s[d16[0] == 0] == 1.0).all() and (s[d16[0] > 0] == np.float32(0.1)).all()
+    ref = orc.OFrame(g, d, s, K_KINECT_IR, 4, 1)
+    obj = orc.OFrame(*fl[1], K_KINECT_IR, 4, 1)
+    xi, log = orc.track(obj, ref)
+    assert np.isfinite(xi).all() and sum(log["n_iter"]) >= 4
+
+
+@pytest.mark.gpu
+def test_sensor_depth_tracking_on_kinect_frames_matches_the_oracle_at_every_iteration():
+    """Tracker::track (tracker.cpp:22-85) as odometrizeUsingDepth runs it (Frame(g,d,s,K,4,1), sigma 0.1 / 1.0, INVALID gray in the
+    depth holes: transform.cpp:60-76) on real Kinect IR + depth frames with 6 % holes.  Along the GPU's own trajectory every
+    iteration is checked against the oracle at the same input pose: contributing-pixel count exact, residual 1e-4, and the
+    update solves the oracle's normal equations to a backward error <= 2e-6 (also where the diverged pose leaves a handful of pixels and a singular system); first-iteration masks bit-exact on every level;
+    the raw (u8 + u16) entry point equals the float one bit for bit."""
+    import dvo_amd as dvo
+    g8, d16, fl = _kinect_sequence()
+    cfg = dvo.default_config(gn_pixels_per_thread=4)
+    vo_raw = dvo.VisualOdometry(K_KINECT_IR, 512, 424, cfg=cfg)
+    vo_flt = dvo.VisualOdometry(K_KINECT_IR, 512, 424, cfg=cfg)
+    n_checked = 0
+    for i in range(4):
+        Ta = vo_raw.odometrizeUsingDepthRaw(g8[i], d16[i])
+        Tb = vo_flt.odometrizeUsingDepth(*fl[i])
+        np.testing.assert_array_equal(Ta, Tb)
+        if i == 0:
+            continue
+        lg = vo_flt.lastTrackLog()
+        ref = orc.OFrame(*fl[i - 1], K_KINECT_IR, 4, 1)
+        obj = orc.OFrame(*fl[i], K_KINECT_IR, 4, 1)
+        xi = np.zeros(6, np.float32)
+        for l in range(4):
+            r = dvo.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, cfg=cfg, want_mask=True)
+            o = orc.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, want_mask=True)
+            np.testing.assert_array_equal(r["mask"], o["mask"])
+            for it in range(lg["n_iter"][l]):
+                o = orc.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l)
+                assert o["n_valid"] == lg["n_valid"][l][it], (i, l, it)
+                if o["n_valid"] == 0:     # the over-relaxed iteration (sigma 0.1: gain 10) threw the pose so far that nothing projects into
+                    assert lg["residual"][l][it] == np.float32(-1)           # the image: residual -1, zero update (optimize.cpp:92-93)
+                    np.testing.assert_array_equal(lg["xi_after"][l][it], xi)
+                    n_checked += 1
+                    continue
+                np.testing.assert_allclose(lg["residual"][l][it], o["residual"], rtol=1e-4)
+                r = dvo.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, cfg=cfg)   # the same step as an operator call
+                assert r["n_valid"] == o["n_valid"]
+                upd = r["xi_update"].astype(np.float64)
+                H = orc.upper_to_full(o["H"])
+                back = np.abs(H @ upd - o["g"]).max() / (np.abs(H) @ np.abs(upd) + np.abs(o["g"])).max()
+                assert back <= 2e-6, (i, l, it, back)
+                np.testing.assert_allclose(lg["xi_after"][l][it], r["xi_next"], rtol=0, atol=1e-6 * max(1.0, float(np.abs(r["xi_next"]).max())))
+                xi = lg["xi_after"][l][it]
+                n_checked += 1
+    vo_raw.close(); vo_flt.close()
+    assert n_checked >= 12
