@@ -512,3 +512,28 @@ def test_batch_prefetch_changes_no_result():
         bt.close()
     assert np.abs(res[0]).max() > 1e-4
     np.testing.assert_array_equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("w,h", [(192, 160), (96, 320)])
+def test_narrow_2d_tiles_parity(w, h):
+    """The 32- and 16-column 2-D tiles of k_track_gn (GnTiling: widths that are multiples of 32 / 16 but not 64) at 4 pixels per
+    thread -- until now only covered by the host-compiled geometry check: 192x160 -> levels 96x80 (32-wide tiles) and 192x160 (64);
+    96x320 -> 48x160 (16-wide tiles) and 96x320 (32).  Masks bit-exact, H / update within the usual tolerances, fixed-iteration
+    track against the oracle."""
+    from dvo_amd import synth
+    K = np.array(synth.K_640, np.float32).copy()
+    K[0] *= w / 640.0; K[1] *= h / 480.0
+    g, d, s, _ = synth.sequence(2, width=w, height_px=h, K=K, seed=5, sigma_value=0.5)
+    g, d, s = g.numpy(), d.numpy(), s.numpy()
+    ref = orc.OFrame(g[0], d[0], s[0], K, 2, 0)
+    obj = orc.OFrame(g[1], d[1], s[1], K, 2, 0)
+    rg = ref.gray(1); rg[h // 2:h // 2 + 3, w // 3:w // 3 + 9] = INV     # INVALID taps inside the image too
+    xi = np.array([0.004, -0.003, 0.002, 0.003, -0.002, 0.004], np.float32)
+    cfg = dvo.default_config(crop_enable=0, gn_pixels_per_thread=4)
+    for l in range(2):
+        _gn_compare(obj.gray(l), rg if l == 1 else ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l, cfg=cfg, crop=False)
+    cfg = dvo.default_config(crop_enable=0, gn_pixels_per_thread=4, fixed_iterations=3)
+    xo, lo = orc.track(obj, ref, crop=False, fixed_iters=3)
+    xg, lg = dvo.track(g[1], g[0], d[0], s[0], K, 2, 0, cfg=cfg)
+    assert lg["n_iter"][:2] == [3, 3] == lo["n_iter"]
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
