@@ -543,6 +543,25 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
                       "keyframe_fraction_of_timed_frames": keys, "iterations_per_level_seq0": log0["n_iter"],
                       "keyframes_created_seq0": kf0["n_keyframes"], "mean_valid_updates_last_frame": float(np.mean(vu)),
                       "poses_finite": bool(torch.isfinite(poses_out).all().item()), "datagen_s": round(t_gen, 2)}}
+    if a.pcie_steps > 0:   # co-headline: every frame streamed from pinned host memory, every pose copied back
+        PB = min(B, 1024)
+        hb = dvo.MonoBatch(PB, K, W, H, ring_keyframes=a.ring, cfg=dvo.default_config(device=local, stream=stream, rng_seed=1))
+        host = [gray[f, :PB].cpu().pin_memory() for f in range(min(F, 3))]
+        xi_dev = torch.zeros((a.pcie_steps, PB, 6), dtype=torch.float32, device=dev)
+        xi_pin = torch.zeros((a.pcie_steps, PB, 6), dtype=torch.float32).pin_memory()
+        hb.odometrize_host(host[0].numpy()); hb.odometrize_host(host[1].numpy())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.pcie_steps):
+            hb.odometrize_host(host[ring_index(2 + k, len(host))].numpy())
+            hb.copy_world_poses_device(xi_dev[k].data_ptr())
+            xi_pin[k].copy_(xi_dev[k], non_blocking=True)
+        hb.synchronize()
+        torch.cuda.synchronize()
+        out["value_incl_h2d"] = PB * a.pcie_steps / (time.perf_counter() - t1)
+        out["incl_h2d"] = {"sequences": PB, "frames_streamed_per_sequence": a.pcie_steps, "bytes_per_frame": (1 if raw else 4) * W * H,
+                           "input": "pinned host %s gray (dvo_batch_odometrize_%shost), every world pose copied back per step" % (("u8", "raw_") if raw else ("float32", ""))}
+        hb.close()
     if not a.no_roofline:
         pb, _ = run(1)
         pr = pb.profile()

@@ -242,6 +242,10 @@ struct MonoBatch {
     int set_initial_depth(const float* depth_host, const float* sigma_host);              // one map, broadcast to every sequence
     int set_initial_depth_device(const float* depth_dev, const float* sigma_dev);         // [n_seq][th][tw]
     int odometrize(const FrameInput& in);                                                  // gray [n_seq][h][w] float, or raw u8
+    int odometrize_host(const void* frames, size_t bytes, FrameInput in);                  // the same from host memory (copy stream, 2 slots)
+    struct Stage { DevBuf buf; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; } stage[2];
+    hipStream_t cstream = nullptr;
+    int n_host = 0;
     int top_pixels() const { return g.w[g.top()] * g.h[g.top()]; }
 };
 

@@ -251,15 +251,24 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
         float ssd = 0.0f;
         ptx += dirx;
         pty += diry;
+        // The three samples of a step are independent of each other: all 12 taps are requested before any is used (three gather
+        // round trips in flight instead of one after the other).  The reference's early exit -- the first INVALID sample sets
+        // ssd = 6 and leaves (implement.cpp:128-131) -- is then applied to the loaded values: same result.
+        float sgv[3];
+#pragma unroll
         for (int jj = 0; jj < 3; jj++) {
             const float kf = (float)(jj - 1);
-            const float tx = ptx + dirx * kf, ty = pty + diry * kf;
-            const float sgv = get_subpixel_dense(bg, tx, ty);
-            if (is_invalid(sgv)) { ssd = 6.0f; break; }
-            const float diff = sgv - og;
-            const int aw = 3 - abs(jj - 2);
-            ssd = (float)((double)ssd + 1.0 * aw / 3 * (double)(diff * diff));  // implement.cpp:134
+            sgv[jj] = get_subpixel_dense(bg, ptx + dirx * kf, pty + diry * kf);
         }
+        bool any_invalid = false;
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            any_invalid = any_invalid | is_invalid(sgv[jj]);
+            const float diff = sgv[jj] - og;
+            const int aw = 3 - abs(jj - 2);
+            ssd = (float)((double)ssd + 1.0 * aw / 3 * (double)(diff * diff));  // implement.cpp:134 (discarded when a sample is INVALID)
+        }
+        if (any_invalid) ssd = 6.0f;
         if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
         if (count++ > 100) break;
     }

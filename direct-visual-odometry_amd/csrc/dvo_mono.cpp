@@ -13,6 +13,11 @@ namespace dvo {
 
 MonoBatch::~MonoBatch()
 {
+    if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
+    for (auto& st : stage) {
+        if (st.copied) (void)hipEventDestroy(st.copied);
+        if (st.consumed) (void)hipEventDestroy(st.consumed);
+    }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -68,6 +73,32 @@ int MonoBatch::set_initial_depth_device(const float* depth_dev, const float* sig
     DVO_HIP(hipMemcpyAsync(ref.sigma[T], sigma_dev, all, hipMemcpyDeviceToDevice, stream));
     have_init = true;
     return DVO_OK;
+}
+
+int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
+{  // frames of every sequence from host memory: H2D on a copy stream into one of two staging slots (as Batch::push_host_frame)
+    if (!frames) { set_error("null host pointer"); return DVO_ERR_BAD_ARGUMENT; }
+    DVO_TRY(select_device(device));
+    if (!cstream) {
+        DVO_HIP(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        for (auto& st : stage) {
+            DVO_HIP(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+            DVO_HIP(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+        }
+    }
+    trk.adaptive = false;   // (the host must not be held inside track(): the next frame's transfer is queued meanwhile)
+    Stage& st = stage[n_host & 1];
+    n_host++;
+    if (st.buf.bytes < bytes) DVO_TRY(st.buf.alloc(bytes));
+    if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
+    DVO_HIP(hipMemcpyAsync(st.buf.p, frames, bytes, hipMemcpyHostToDevice, cstream));
+    DVO_HIP(hipEventRecord(st.copied, cstream));
+    DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));
+    if (in.raw()) in.rgb = st.buf.as<uint8_t>(); else in.gray = st.buf.as<float>();
+    const int rc = odometrize(in);
+    DVO_HIP(hipEventRecord(st.consumed, stream));
+    st.used = true;
+    return rc;
 }
 
 int MonoBatch::odometrize(const FrameInput& in)
@@ -201,6 +232,23 @@ int dvo_batch_odometrize_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int ch
     FrameInput in;
     in.rgb = rgb_dev; in.channels = channels;
     return b->mono->odometrize(in);
+}
+
+int dvo_batch_odometrize_host(dvo_batch* b, const float* gray)
+{
+    DVO_NEED_MONO(b);
+    FrameInput in;
+    in.gray = gray;
+    return b->mono->odometrize_host(gray, sizeof(float) * (size_t)b->mono->n_seq * b->mono->g.src_w * b->mono->g.src_h, in);
+}
+
+int dvo_batch_odometrize_raw_host(dvo_batch* b, const uint8_t* rgb, int channels)
+{
+    DVO_NEED_MONO(b);
+    if (channels != 1 && channels != 3 && channels != 4) { set_error("bad channel count"); return DVO_ERR_BAD_ARGUMENT; }
+    FrameInput in;
+    in.rgb = rgb; in.channels = channels;
+    return b->mono->odometrize_host(rgb, (size_t)channels * b->mono->n_seq * b->mono->g.src_w * b->mono->g.src_h, in);
 }
 
 int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe)

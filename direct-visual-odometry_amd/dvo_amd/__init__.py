@@ -70,6 +70,7 @@ EXPORTS = [
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
     "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
     "dvo_batch_push_raw_device", "dvo_batch_prefetch_raw_device", "dvo_batch_push_raw_host", "dvo_batch_odometrize_raw_device",
+    "dvo_batch_odometrize_host", "dvo_batch_odometrize_raw_host",
     "dvo_batch_create_mono", "dvo_batch_set_initial_depth", "dvo_batch_set_initial_depth_device", "dvo_batch_odometrize_device",
     "dvo_batch_world_poses", "dvo_batch_copy_world_poses_device", "dvo_batch_keyframe_get",
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
@@ -576,6 +577,16 @@ class MonoBatch:
     def odometrize_raw_device(self, rgb_ptr, channels):
         """Device pointer (int) to [n_seq, H, W(, C)] uint8 frames (gray / RGB / RGBA)."""
         _check(lib().dvo_batch_odometrize_raw_device(self._p, C.c_void_p(rgb_ptr), int(channels)))
+
+    def odometrize_host(self, frames):
+        """Host frames [n_seq, H, W]: float32 gray, or uint8 gray / [n_seq, H, W, C] uint8 colour (raw, converted on the device)."""
+        a = np.ascontiguousarray(frames)
+        assert a.shape[:3] == (self.n_seq, self.height, self.width)
+        if a.dtype == np.uint8:
+            _check(lib().dvo_batch_odometrize_raw_host(self._p, a.ctypes.data_as(C.c_void_p), 1 if a.ndim == 3 else a.shape[3]))
+        else:
+            a = f32(a)
+            _check(lib().dvo_batch_odometrize_host(self._p, fp(a)))
 
     def world_poses(self):
         xi = np.zeros((self.n_seq, 6), np.float32); T = np.zeros((self.n_seq, 16), np.float32); key = np.zeros(self.n_seq, np.int32)

@@ -181,6 +181,9 @@ int dvo_batch_set_initial_depth_device(dvo_batch* b, const float* depth_dev, con
 int dvo_batch_odometrize_device(dvo_batch* b, const float* gray_dev);
 /* same from raw u8 frames [n_seq][height][width][channels] (channels 1 / 3 / 4), converted inside the pyramid kernel */
 int dvo_batch_odometrize_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels);
+/* the same two from host memory (copy stream + two staging slots, as dvo_batch_push_host) */
+int dvo_batch_odometrize_host(dvo_batch* b, const float* gray);
+int dvo_batch_odometrize_raw_host(dvo_batch* b, const uint8_t* rgb, int channels);
 /* world twists [n_seq][6], world poses exp(xi) [n_seq][16] (system.hpp:73) and keyframe flags [n_seq] of the last frame
  * (synchronises); any pointer may be NULL.  _device: asynchronous device-to-device copies on the handle's stream. */
 int dvo_batch_world_poses(dvo_batch* b, float* xi_world, float* T_world, int* is_keyframe);

@@ -288,6 +288,13 @@ def test_mono_batch_raw_equals_float():
         res.append(out)
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+    # the host entry points (copy stream, two staging slots, fixed schedule) give the same bits
+    mb = dvo.MonoBatch(B, K640, 640, 480, cfg=dvo.default_config(rng_seed=2))
+    for k in range(4):
+        g8 = np.stack([np.clip(np.rint(g[(k + b) % 4] * 255), 0, 255).astype(np.uint8) for b in range(B)])
+        mb.odometrize_host(g8)
+        np.testing.assert_array_equal(mb.world_poses()[1], res[1][k])
+    mb.close()
 
 
 # ---------------------------------------------------------------- whole-trajectory agreement (BASELINE.json: ATE within 1e-3 m of the reference)
