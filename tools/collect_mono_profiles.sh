@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd $R && python3 bench.py --workload syn640-mono > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err && echo "bench done" &&
 cd /tmp && export TMPDIR=/tmp &&
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --workload syn640-mono --no-cpu-baseline --no-roofline > /tmp/prof_$TAG.json 2> /tmp/prof_$TAG.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --workload syn640-mono --no-cpu-baseline --no-roofline --pcie-steps 0 > /tmp/prof_$TAG.json 2> /tmp/prof_$TAG.err &&
 cp /tmp/prof_$TAG/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv && echo "stats done" &&
 OUT=/tmp/pmcm_$$ && i=0 &&
 for SET in \
@@ -14,6 +14,6 @@ for SET in \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --kernel-include-regex "k_depth_update|k_propagate|k_regularize|k_promote|k_pyramid" --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload syn640-mono --batch 1024 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT.log; }
+  rocprofv3 --pmc $SET --kernel-include-regex "k_depth_update|k_propagate|k_regularize|k_promote|k_pyramid" --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload syn640-mono --batch 1024 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --pcie-steps 0 > $OUT.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT.log; }
 done
 python3 $R/tools/pmc_summary.py "$OUT/p*/*/*counter_collection.csv" > $R/gpurun_out/${TAG}_mapping_pmc.txt && echo "pmc done"
