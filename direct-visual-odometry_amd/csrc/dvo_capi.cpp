@@ -112,6 +112,12 @@ int dvo_vo_odometrize(dvo_vo* vo, const float* gray, float T_world[16], int* is_
     return vo->impl.odometrize(gray, T_world, is_keyframe);
 }
 
+int dvo_vo_odometrize_raw(dvo_vo* vo, const uint8_t* rgb, int channels, float T_world[16], int* is_keyframe)
+{
+    if (!vo || !rgb) return DVO_ERR_BAD_ARGUMENT;
+    return vo->impl.odometrize(nullptr, T_world, is_keyframe, rgb, channels);
+}
+
 int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, const float* sigma, float T_rel[16])
 {
     if (!vo) return DVO_ERR_BAD_ARGUMENT;

@@ -664,17 +664,27 @@ int VisualOdometry::map_regularize(Keyframe& kf)
     return DVO_OK;
 }
 
-int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key)
-{  // system.hpp:44-74
-    if (!gray || !T_world) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
+int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key, const uint8_t* raw, int raw_channels)
+{  // system.hpp:44-74; `raw` != nullptr: the frame arrives as u8 gray / RGB(A) and is converted while the pyramid is built
+    if ((!gray && !raw) || !T_world) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
+    if (raw && raw_channels != 1 && raw_channels != 3 && raw_channels != 4) { set_error("bad channel count"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     if (!trkM_ready) { DVO_TRY(trkM.init(geoM, 1, cfg)); trkM_ready = true; }
-    DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
+    FrameInput fin;
+    if (raw) {
+        const size_t px = (size_t)w * h;
+        if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
+        DVO_HIP(hipMemcpyAsync(raw_rgb.p, raw, px * (size_t)raw_channels, hipMemcpyHostToDevice, stream));
+        fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
+    } else {
+        DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
+        fin.gray = in_gray.as<float>();
+    }
     if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg)); }
     Keyframe& frame = *scratch;
     frame.id = ++latest_id;
     for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
-    build_pyramid(frame.fs, in_gray.as<float>(), nullptr, nullptr, stream);
+    build_pyramid(frame.fs, fin, stream);
     if (is_key) *is_key = 0;
     const int T = geoM.top();
     const size_t tn = (size_t)geoM.w[T] * geoM.h[T];

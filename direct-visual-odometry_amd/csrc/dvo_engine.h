@@ -167,7 +167,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     dvo_track_log last_log;
     ~VisualOdometry();
     int init(const float K9[9], int width, int height, const dvo_config* c);
-    int odometrize(const float* gray, float T_world[16], int* is_key);
+    int odometrize(const float* gray, float T_world[16], int* is_key, const uint8_t* raw = nullptr, int raw_channels = 0);
     int odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16]);
     int odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16]);
     int odometrize_depth_staged(float T_rel[16], const struct FrameInput* raw = nullptr);  // frame already staged on the device

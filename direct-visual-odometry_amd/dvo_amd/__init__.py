@@ -65,7 +65,7 @@ class GnProfile(C.Structure):
 EXPORTS = [
     "dvo_config_default", "dvo_version", "dvo_status_string", "dvo_last_error", "dvo_device_count",
     "dvo_vo_create", "dvo_vo_destroy", "dvo_vo_set_initial_depth", "dvo_vo_init_keyframe", "dvo_vo_odometrize",
-    "dvo_vo_odometrize_depth", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
+    "dvo_vo_odometrize_depth", "dvo_vo_odometrize_raw", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
     "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
     "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
@@ -407,6 +407,14 @@ class VisualOdometry:
     def odometrize(self, gray):
         g = f32(gray); T = np.zeros(16, np.float32); key = C.c_int(0)
         _check(lib().dvo_vo_odometrize(self._p, fp(g), fp(T), C.byref(key)))
+        return T.reshape(4, 4), bool(key.value)
+
+    def odometrizeRaw(self, rgb_u8):
+        """odometrize() fed with a raw uint8 frame [H, W] or [H, W, C] (converted on the device)."""
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        ch = 1 if rgb.ndim == 2 else rgb.shape[2]
+        T = np.zeros(16, np.float32); key = C.c_int(0)
+        _check(lib().dvo_vo_odometrize_raw(self._p, rgb.ctypes.data_as(C.c_void_p), ch, fp(T), C.byref(key)))
         return T.reshape(4, 4), bool(key.value)
 
     def odometrizeUsingDepth(self, gray, depth, sigma):

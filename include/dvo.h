@@ -86,6 +86,9 @@ int dvo_vo_init_keyframe(dvo_vo* vo, const float* gray, const float* depth, cons
 /* cv::Mat1f odometrize(const cv::Mat1f& gray), system.hpp:44-74 -> 4x4 world pose exp(m_xi).
  * is_keyframe (optional) receives 1 when the frame was promoted to keyframe. */
 int dvo_vo_odometrize(dvo_vo* vo, const float* gray, float T_world[16], int* is_keyframe);
+/* the same fed with a raw u8 frame [height][width][channels] (channels 1 gray / 3 R,G,B / 4 R,G,B,A): cv::imread's output before
+ * Loader::getNormalizedImages (src/core/loader.cpp:55-62); converted on the device, bit-identical to the float entry point */
+int dvo_vo_odometrize_raw(dvo_vo* vo, const uint8_t* rgb, int channels, float T_world[16], int* is_keyframe);
 /* cv::Mat1f odometrizeUsingDepth(gray, depth, sigma), system.hpp:77-93 -> 4x4 RELATIVE pose. */
 int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, const float* sigma, float T_rel[16]);
 

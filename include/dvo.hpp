@@ -73,6 +73,15 @@ public:
         if (is_keyframe) *is_keyframe = key != 0;
         return T;
     }
+    // the same from a raw u8 frame (gray / R,G,B / R,G,B,A), converted on the device
+    Mat4 odometrizeRaw(const uint8_t* rgb, int channels, bool* is_keyframe = nullptr)
+    {
+        Mat4 T;
+        int key = 0;
+        check(dvo_vo_odometrize_raw(vo_, rgb, channels, T.data(), &key));
+        if (is_keyframe) *is_keyframe = key != 0;
+        return T;
+    }
     // cv::Mat1f odometrizeUsingDepth(gray, depth, sigma), system.hpp:77-93: 4x4 relative pose
     Mat4 odometrizeUsingDepth(const float* gray, const float* depth, const float* sigma)
     {

@@ -288,6 +288,15 @@ def test_mono_batch_raw_equals_float():
         res.append(out)
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+    # ... and so does a single dvo_vo handle fed raw frames (dvo_vo_odometrize_raw) against the float entry point
+    va = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(rng_seed=2)); vb = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(rng_seed=2))
+    for k in range(4):
+        g8 = np.clip(np.rint(g[k] * 255), 0, 255).astype(np.uint8)
+        Ta, ka = va.odometrizeRaw(g8)
+        Tb, kb = vb.odometrize(dvo.ingest(g8))
+        np.testing.assert_array_equal(Ta, Tb)
+        assert ka == kb
+    va.close(); vb.close()
     # the host entry points (copy stream, two staging slots, fixed schedule) give the same bits
     mb = dvo.MonoBatch(B, K640, 640, 480, cfg=dvo.default_config(rng_seed=2))
     for k in range(4):
