@@ -395,9 +395,10 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
             const int first = (it == 0) ? 1 : 0;
             // Stay `ahead` iterations ahead of the GPU: wait until launch it-ahead of this level has reported, and stop the level
             // if it had no active sequence -- every later launch of the level would be empty.  Skipping empty launches
-            // changes no result.  (2 for a few sequences, where an iteration is ~16 us of latency and every empty launch
-            // counts; 4 for batches, whose short coarse-level iterations must never find the queue empty.)
-            const int ahead = n_seq <= 8 ? 2 : 4;
+            // changes no result.  Two iterations ahead for every batch size: a batch iteration takes >= 20 us on the GPU, the host
+            // needs ~10 us to see a progress word and queue the next pair, and every iteration queued beyond the last useful one
+            // is an empty launch pair (~15 us): measured +1.6 % (mono, 1 iteration per level) / +0.7 % (sensor depth) against 4.
+            const int ahead = 2;
             if (adaptive && !fused[level] && it >= ahead) {
                 volatile int* pw = prog_h + level * DVO_MAX_ITERATIONS + (it - ahead);
                 long spins = 0;
