@@ -255,10 +255,25 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
         // round trips in flight instead of one after the other).  The reference's early exit -- the first INVALID sample sets
         // ssd = 6 and leaves (implement.cpp:128-131) -- is then applied to the loaded values: same result.
         float sgv[3];
+        // Interior fast path: pt in [2, w-3) x [2, h-3) and |dir| <= 1 (+ an ulp) put all three samples' 2 x 2 footprints inside the
+        // image, where Convert::getSubpixelFromDense (convert.cpp:77-105) has no clamp, no range test and no INVALID exit: the same
+        // truncation, fractions and blend4() without ~20 instructions of bounds logic per sample.  Wave-uniform choice.
+        const bool inner = (ptx >= 2.0f) & (ptx < (float)(w - 3)) & (pty >= 2.0f) & (pty < (float)(h - 3));
+        if (__ballot(!inner) == 0ull) {
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) {
-            const float kf = (float)(jj - 1);
-            sgv[jj] = get_subpixel_dense(bg, ptx + dirx * kf, pty + diry * kf);
+            for (int jj = 0; jj < 3; jj++) {
+                const float kf = (float)(jj - 1);
+                const float px = ptx + dirx * kf, py = pty + diry * kf;
+                const int x0 = (int)px, y0 = (int)py;
+                const float* q = born_gray + (y0 * w + x0);
+                sgv[jj] = blend4(q[0], q[1], q[w], q[w + 1], px - (float)x0, py - (float)y0);
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++) {
+                const float kf = (float)(jj - 1);
+                sgv[jj] = get_subpixel_dense(bg, ptx + dirx * kf, pty + diry * kf);
+            }
         }
         bool any_invalid = false;
 #pragma unroll
