@@ -227,6 +227,17 @@ void launch_promote(const PromoteArgs& a, hipStream_t s);
 void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s);  // dst[seq][i] = src[i]
 void launch_propagate_batch(const PropArgs& a, hipStream_t s);
 void launch_regularize_batch(const float* depth, const float* sigma, int w, int h, int n_seq, float* out, hipStream_t s);
+// Mapper::regularize + Frame::updateDepth / updateDepthSigma (mapper.cpp:139-144, frame.cpp:39-61) in one pass over the top level:
+// the regularized depth goes to `depth_top_out` (a second top-level buffer: the stencil reads the old one) and, with the current
+// sigma, to every lower level together with 1/depth and the weight.
+struct RegDecArgs {
+    const float* depth; const float* sigma;   // top level [n_seq][h][w], read only
+    float* depth_top_out;                     // [n_seq][h][w]
+    float* depth_lv[DVO_MAX_LEVELS]; float* sigma_lv[DVO_MAX_LEVELS]; float* iz[DVO_MAX_LEVELS]; float* wgt[DVO_MAX_LEVELS];  // per level (top: iz, wgt only)
+    int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS], levels, n_seq;
+    float step[DVO_MAX_LEVELS], sigma_min, sigma_max;
+};
+void launch_regularize_redecimate(const RegDecArgs& a, hipStream_t s);
 
 void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s);
 void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s);

@@ -186,6 +186,43 @@ __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ de
     out_all[base + i] = gd < 6.0f ? gd : 6.0f;
 }
 
+// k_regularize_redecimate: k_regularize and the re-decimation that follows it in the mono pipeline, one pass.  Same operations per
+// pixel as k_regularize + k_pyramid(culls = 0, depth and sigma): the regularized value is written to a second top-level buffer (the
+// 5-point stencil of the neighbours still reads the old one) and decimated on the spot into every level it lands on, with sigma,
+// 1/depth and the Gauss-Newton weight -- saves one launch and the 8 B/px round trip of the intermediate map.
+__global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
+{
+    const int T = a.levels - 1, w = a.w[T], h = a.h[T];
+    int seq, i;
+    if (!seq_pixel(w * h, seq, i)) return;
+    const size_t base = (size_t)seq * w * h;
+    const float* __restrict__ depth = a.depth + base;
+    const float* __restrict__ sigma = a.sigma + base;
+    const int y = i / w, x = i - y * w;
+    const float s0 = sigma[i];
+    float gd = depth[i], gs = s0;
+    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
+    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
+    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
+    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
+    const float nd = gd < 6.0f ? gd : 6.0f;                       // implement.cpp:178
+    a.depth_top_out[base + i] = nd;                               // top level: the map itself (cullImage(src, 0) aliases, convert.cpp:9-10)
+    __builtin_nontemporal_store(1.0f / nd, a.iz[T] + base + i);
+    __builtin_nontemporal_store(gn_weight(a.step[T], a.sigma_min, a.sigma_max, s0), a.wgt[T] + base + i);
+    const float vd = pass_valid(nd), vs = pass_valid(s0);
+    for (int t = 1; t < a.levels; t++) {                          // lower levels keep pixels whose coordinates are multiples of 2^t
+        const int msk = (1 << t) - 1;
+        if ((x & msk) | (y & msk)) break;
+        const int l = T - t, lx = x >> t, ly = y >> t;
+        if (lx >= a.w[l] || ly >= a.h[l]) continue;
+        const size_t o = (size_t)seq * a.w[l] * a.h[l] + (size_t)ly * a.w[l] + lx;
+        a.depth_lv[l][o] = vd;
+        a.sigma_lv[l][o] = vs;
+        a.iz[l][o] = 1.0f / vd;
+        a.wgt[l][o] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, vs);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One reference pixel of Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214).  The per-keyframe
 // relative poses come from k_age_table (never a per-pixel exp/log).
@@ -495,6 +532,12 @@ void launch_propagate(const float* ref_depth, const float* ref_sigma, const floa
 void launch_regularize_batch(const float* depth, const float* sigma, int w, int h, int n_seq, float* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_regularize, dim3(cdiv_u(w * h, 256) * (unsigned)n_seq), dim3(256), 0, s, depth, sigma, w, h, out);
+}
+
+void launch_regularize_redecimate(const RegDecArgs& a, hipStream_t s)
+{
+    const int T = a.levels - 1;
+    hipLaunchKernelGGL(k_regularize_redecimate, dim3(cdiv_u(a.w[T] * a.h[T], 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s)

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "dvo_engine.h"
 
@@ -175,8 +176,21 @@ int MonoBatch::odometrize(const FrameInput& in)
     // Mapper::regularize (mapper.cpp:139-144) of the newest keyframe, then Frame::updateDepthSigma / updateDepth (frame.cpp:39-61):
     // every level of depth and sigma is a decimation of the top maps, so ONE pass re-derives both pyramids (and 1/depth, the
     // weight) from the regularized depth and the current sigma -- the same values the reference's two re-decimations leave.
-    launch_regularize_batch(ref.depth[T], ref.sigma[T], tw, th, n_seq, tmp.as<float>(), stream);
-    redecimate(ref, tmp.as<float>(), ref.sigma[T], stream);
+    {
+        RegDecArgs ra;
+        memset(&ra, 0, sizeof ra);
+        ra.depth = ref.depth[T]; ra.sigma = ref.sigma[T];
+        if (!depth_alt) depth_alt = tmp.as<float>();
+        ra.depth_top_out = depth_alt;
+        for (int l = 0; l < g.levels; l++) {
+            ra.w[l] = g.w[l]; ra.h[l] = g.h[l];
+            ra.depth_lv[l] = ref.depth[l]; ra.sigma_lv[l] = ref.sigma[l]; ra.iz[l] = ref.iz[l]; ra.wgt[l] = ref.wgt[l];
+            ra.step[l] = ref.step[l];
+        }
+        ra.levels = g.levels; ra.n_seq = n_seq; ra.sigma_min = ref.sigma_min; ra.sigma_max = ref.sigma_max;
+        launch_regularize_redecimate(ra, stream);
+        std::swap(ref.depth[T], depth_alt);   // the top-level depth map alternates between the arena block and `tmp`
+    }
     DVO_HIP(hipGetLastError());
     return DVO_OK;
 }
