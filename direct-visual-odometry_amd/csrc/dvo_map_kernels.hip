@@ -118,54 +118,76 @@ __global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
 //   pass 0: outputs <- (1, 1, 0), owner <- -1;  pass 1: owner[target] = max(source index);
 //   pass 2: every target pulls depth/sigma/age from its owning source pixel.
 // ------------------------------------------------------------------------------------------------
+// (four pixels per thread: on most frames most sequences take the other branch, and a workgroup that only finds that out costs
+//  as much to dispatch as one that works -- a quarter of the workgroups)
+#define DVO_PROP_PER_THREAD 4
+__device__ __forceinline__ int prop_chunk(int npix, int& seq)   // first pixel of this thread (stride 256), sequence of the workgroup
+{
+    const unsigned bps = ((unsigned)npix + 256u * DVO_PROP_PER_THREAD - 1u) / (256u * DVO_PROP_PER_THREAD);
+    seq = (int)(blockIdx.x / bps);
+    return (int)(blockIdx.x - (unsigned)seq * bps) * (256 * DVO_PROP_PER_THREAD) + (int)threadIdx.x;
+}
+
 __global__ void __launch_bounds__(256) k_propagate_init(PropArgs a)
 {
-    int seq, i;
-    const int n = a.w * a.h;
-    if (!seq_pixel(n, seq, i)) return;
+    int seq;
+    const int n = a.w * a.h, i0 = prop_chunk(n, seq);
     if (a.meta && !a.meta[seq].need) return;
-    const size_t o = (size_t)seq * n + i;
-    a.depth[o] = 1.0f; a.sigma[o] = 1.0f; a.age[o] = 0.0f; a.owner[o] = -1;
+#pragma unroll
+    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+        const int i = i0 + k * 256;
+        if (i >= n) break;
+        const size_t o = (size_t)seq * n + i;
+        a.depth[o] = 1.0f; a.sigma[o] = 1.0f; a.age[o] = 0.0f; a.owner[o] = -1;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_propagate_owner(PropArgs a)
 {
-    int seq, i;
-    const int w = a.w, h = a.h, n = w * h;
-    if (!seq_pixel(n, seq, i)) return;
+    int seq;
+    const int w = a.w, h = a.h, n = w * h, i0 = prop_chunk(n, seq);
     if (a.meta && !a.meta[seq].need) return;
     const Pose pose = a.meta ? a.meta[seq].rel_pose : a.pose;   // wave-uniform
-    const int y = i / w, x = i - y * w;
-    const float rd = a.ref_depth[(size_t)seq * n + i];
-    if (is_epsilon(rd)) return;
-    float pu, pv;
-    warp(pose, a.k, (float)x, (float)y, rd, pu, pv);
-    int qx, qy;
-    if (!round_coord(pu, qx) || !round_coord(pv, qy)) return;
-    if (qx < 0 || w <= qx || qy < 0 || h <= qy) return;
-    atomicMax(&a.owner[(size_t)seq * n + qy * w + qx], i);
+#pragma unroll
+    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+        const int i = i0 + k * 256;
+        if (i >= n) break;
+        const int y = i / w, x = i - y * w;
+        const float rd = a.ref_depth[(size_t)seq * n + i];
+        if (is_epsilon(rd)) continue;
+        float pu, pv;
+        warp(pose, a.k, (float)x, (float)y, rd, pu, pv);
+        int qx, qy;
+        if (!round_coord(pu, qx) || !round_coord(pv, qy)) continue;
+        if (qx < 0 || w <= qx || qy < 0 || h <= qy) continue;
+        atomicMax(&a.owner[(size_t)seq * n + qy * w + qx], i);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
 {
-    int seq, o;
-    const int n = a.w * a.h;
-    if (!seq_pixel(n, seq, o)) return;
+    int seq;
+    const int n = a.w * a.h, o0 = prop_chunk(n, seq);
     if (a.meta && !a.meta[seq].need) return;
     const float tz = a.meta ? a.meta[seq].rel_xi[2] : a.tz;
     const size_t base = (size_t)seq * n;
-    const int i = a.owner[base + o];
-    if (i < 0) return;
-    const float rd = a.ref_depth[base + i];
-    float s = a.ref_sigma[base + i];
-    const float d0 = rd < 0.01f ? 0.01f : rd;
-    const float d1 = d0 + tz;
-    const float q = d1 / d0;
-    const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
-    s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
-    a.depth[base + o] = d1 < 0.0f ? 0.0f : d1;
-    a.sigma[base + o] = s;
-    a.age[base + o] = a.ref_age[base + i] + 1.0f;
+#pragma unroll
+    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+        const int o = o0 + k * 256;
+        if (o >= n) break;
+        const int i = a.owner[base + o];
+        if (i < 0) continue;
+        const float rd = a.ref_depth[base + i];
+        float s = a.ref_sigma[base + i];
+        const float d0 = rd < 0.01f ? 0.01f : rd;
+        const float d1 = d0 + tz;
+        const float q = d1 / d0;
+        const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
+        s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
+        a.depth[base + o] = d1 < 0.0f ? 0.0f : d1;
+        a.sigma[base + o] = s;
+        a.age[base + o] = a.ref_age[base + i] + 1.0f;
+    }
 }
 
 // Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
@@ -513,7 +535,7 @@ void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStr
 
 void launch_propagate_batch(const PropArgs& a, hipStream_t s)
 {
-    const dim3 grid(cdiv_u(a.w * a.h, 256) * (unsigned)a.n_seq);
+    const dim3 grid(cdiv_u(a.w * a.h, 256 * DVO_PROP_PER_THREAD) * (unsigned)a.n_seq);
     hipLaunchKernelGGL(k_propagate_init, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_owner, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_pull, grid, dim3(256), 0, s, a);
