@@ -353,10 +353,10 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     return a;
 }
 
-void Tracker::launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const
+void Tracker::launch_gn(const GnArgs& a, int level, int count, hipStream_t s, int grid_seqs) const
 {
     if (tile_margin > 0) launch_track_gn_tile(a, count, ppt[level], s);
-    else launch_track_gn(a, count, ppt[level], group[level], s);
+    else launch_track_gn(a, count, ppt[level], group[level], s, grid_seqs);
 }
 
 int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
@@ -399,6 +399,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
             // needs ~10 us to see a progress word and queue the next pair, and every iteration queued beyond the last useful one
             // is an empty launch pair (~15 us): measured +1.6 % (mono, 1 iteration per level) / +0.7 % (sensor depth) against 4.
             const int ahead = 2;
+            int active_ub = 0;   // sequences that entered iteration it - ahead: the active set only shrinks within a level, so this bounds the list of `it`
             if (adaptive && !fused[level] && it >= ahead) {
                 volatile int* pw = prog_h + level * DVO_MAX_ITERATIONS + (it - ahead);
                 long spins = 0;
@@ -411,6 +412,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                     __builtin_ia32_pause();
                 }
                 if (*pw - 1 == 0) break;
+                if (!single_launch[level]) active_ub = *pw - 1;
             }
             const GnArgs ga0 = gn_args(obj, ref, level, nullptr, first);
             for (int k = 0; k < subs; k++) {  // launches of the sub-batches interleave on their streams
@@ -463,11 +465,11 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                         ev_pool.emplace_back(e0, e1);
                     }
                     DVO_HIP(hipEventRecord(ev_pool[ev_used].first, sk));
-                    launch_gn(ga, level, nq, sk);
+                    launch_gn(ga, level, nq, sk, active_ub);
                     DVO_HIP(hipEventRecord(ev_pool[ev_used].second, sk));
                     ev_used++;
                 } else {
-                    launch_gn(ga, level, nq, sk);
+                    launch_gn(ga, level, nq, sk, active_ub);
                 }
                 SolveArgs sa;
                 sa.state = state.as<SeqState>() + q0;

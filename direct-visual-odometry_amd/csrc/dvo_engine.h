@@ -117,7 +117,7 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     bool adaptive = false;
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
-    void launch_gn(const GnArgs& a, int level, int count, hipStream_t s) const;  // `a` views `count` sequences
+    void launch_gn(const GnArgs& a, int level, int count, hipStream_t s, int grid_seqs = 0) const;  // `a` views `count` sequences
     // profiling (cfg.profile)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;

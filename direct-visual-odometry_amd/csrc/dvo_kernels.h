@@ -244,7 +244,7 @@ void launch_cull(const float* src, int w, int h, int times, float* dst, hipStrea
 void launch_gradient(const float* img, int w, int h, int xdir, float* out, hipStream_t s);
 void launch_warp_image(const float* gray, const float* depth, int w, int h, const Intr& k, const Pose& pose, float* out, hipStream_t s);
 int  gn_blocks_per_seq(int w, int h, int ppt, int crop);  // = gn_tiling(...).count
-void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s);
+void launch_track_gn(const GnArgs& a, int n_seq, int ppt, int group, hipStream_t s, int grid_seqs = 0);
 void launch_prep_ref(const PrepArgs& a, hipStream_t s);
 // LDS-tiled variant: a.tiles_x/tiles_y/margin/nblk must be set (see gn_tile_geometry)
 void launch_track_gn_tile(const GnArgs& a, int n_seq, int ppt, hipStream_t s);

@@ -1347,7 +1347,7 @@ static void launch_track_gn_t(const GnArgs& a, unsigned tiles, hipStream_t s)
     else hipLaunchKernelGGL((k_track_gn<PPT, G, false>), dim3(g), dim3(256), 0, s, a);
 }
 
-void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_t s)
+void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_t s, int grid_seqs)
 {
     GnArgs a = a0;
     a.n_seq = n_seq;
@@ -1355,7 +1355,10 @@ void launch_track_gn(const GnArgs& a0, int n_seq, int ppt, int group, hipStream_
     a.blk_first = tl.live_first; a.blk_count = tl.live_count;
     a.t_shift = tl.shift; a.x_org = tl.x_org; a.y_org = tl.y_org;
     if (tl.t2d) a.tiles_x = tl.tiles_x;
-    unsigned grid = (unsigned)a.blk_count * (unsigned)n_seq;
+    // grid_seqs: an upper bound of the sequences on the active list (the host knows one from the progress words): the grid then only
+    // holds workgroups that can find a tile -- at 16 384 sequences x 75 tiles an all-empty grid alone costs ~0.35 ms to dispatch
+    const int gs = (grid_seqs > 0 && grid_seqs < n_seq && a.list != nullptr) ? grid_seqs : n_seq;
+    unsigned grid = (unsigned)a.blk_count * (unsigned)gs;
     if (grid == 0) grid = 8;  // (nothing live: the workgroups only clear the next list counter)
     switch (ppt * 10 + group) {
         case 11: launch_track_gn_t<1, 1>(a, grid, s); break;
