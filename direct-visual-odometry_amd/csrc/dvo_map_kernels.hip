@@ -463,12 +463,16 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
 // set's, and its top-level gray enters the keyframe ring (slot n_total % R).  One launch, every segment of every flagged sequence.
 // ------------------------------------------------------------------------------------------------
 #define DVO_PROMOTE_PER_THREAD 8
+// VEC = 4: every segment length is a multiple of 4 floats (the usual geometries), copied as 16-byte accesses; VEC = 1: any length
+template <int VEC>
 __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
 {
+    typedef float fvec __attribute__((ext_vector_type(VEC)));
     int total = a.npix;  // + the ring segment
     for (int g = 0; g < a.n_seg; g++) total += a.count[g];
-    // 2048 elements per workgroup: most sequences do not create a keyframe on a given frame, and a workgroup that only finds that
-    // out costs as much as one that copies -- fewer, fatter workgroups
+    total /= VEC;        // in units of VEC floats
+    // 2048 units per workgroup: most sequences do not create a keyframe on a given frame, and a workgroup that only finds that
+    // out costs as much to dispatch as one that copies -- fewer, fatter workgroups
     const unsigned bps = ((unsigned)total + 256u * DVO_PROMOTE_PER_THREAD - 1u) / (256u * DVO_PROMOTE_PER_THREAD);
     const int seq = (int)(blockIdx.x / bps);
     const MonoSeq& m = a.meta[seq];
@@ -481,15 +485,19 @@ __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
         if (i >= total) break;
         bool done = false;
         for (int g = 0; g < a.n_seg; g++) {
-            if (i < a.count[g]) {
-                const size_t o = (size_t)seq * a.count[g] + i;
-                a.dst[g][o] = a.src[g][o];
+            const int cnt = a.count[g] / VEC;
+            if (i < cnt) {
+                const size_t o = (size_t)seq * cnt + i;
+                reinterpret_cast<fvec*>(a.dst[g])[o] = reinterpret_cast<const fvec*>(a.src[g])[o];
                 done = true;
                 break;
             }
-            i -= a.count[g];
+            i -= cnt;
         }
-        if (!done) a.ring_gray[((size_t)seq * a.R + slot) * a.npix + i] = a.gray_top[(size_t)seq * a.npix + i];
+        if (!done) {
+            const int cnt = a.npix / VEC;
+            reinterpret_cast<fvec*>(a.ring_gray)[((size_t)seq * a.R + slot) * cnt + i] = reinterpret_cast<const fvec*>(a.gray_top)[(size_t)seq * cnt + i];
+        }
     }
 }
 
@@ -524,8 +532,13 @@ void launch_age_table(const AgeTableArgs& a, hipStream_t s)
 void launch_promote(const PromoteArgs& a, hipStream_t s)
 {
     int total = a.npix;
-    for (int g = 0; g < a.n_seg; g++) total += a.count[g];
-    hipLaunchKernelGGL(k_promote, dim3(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    bool vec = (a.npix % 4) == 0 && (reinterpret_cast<uintptr_t>(a.gray_top) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.ring_gray) % 16) == 0;
+    for (int g = 0; g < a.n_seg; g++) {
+        total += a.count[g];
+        vec = vec && (a.count[g] % 4) == 0 && (reinterpret_cast<uintptr_t>(a.src[g]) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.dst[g]) % 16) == 0;
+    }
+    if (vec) hipLaunchKernelGGL(k_promote<4>, dim3(cdiv_u(total / 4, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_promote<1>, dim3(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s)
