@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <dlfcn.h>
+
 namespace dvo {
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -24,6 +26,32 @@ int check_hip(hipError_t e, const char* what)
     if (e == hipErrorOutOfMemory) return DVO_ERR_OUT_OF_MEMORY;
     return DVO_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------------------ tracing (roctx, optional)
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("DVO_TRACE");
+        if (!e || e[0] == '0') return;
+        // rocprofv3 (--marker-trace) intercepts the rocprofiler-sdk flavour of roctx; the legacy libroctx64 serves roctracer tools
+        void* h = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char* name) { if (roctx().push) (void)roctx().push(name); }
+void trace_pop() { if (roctx().pop) (void)roctx().pop(); }
 
 int select_device(int device)
 {
@@ -387,7 +415,10 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     for (int l = 0; l < g.levels; l++) any_single = any_single || single_launch[l];
     int* rep_set = freport.as<int>() + (size_t)(progress_set & 1) * 2 * DVO_MAX_LEVELS * DVO_MAX_ITERATIONS;
     if (any_single) DVO_HIP(hipMemsetAsync(rep_set, 0, sizeof(int) * 2 * DVO_MAX_LEVELS * DVO_MAX_ITERATIONS, s));
+    static const char* const kLevelName[DVO_MAX_LEVELS] = {"track level 0", "track level 1", "track level 2", "track level 3", "track level 4",
+                                                           "track level 5", "track level 6", "track level 7"};
     for (int level = 0; level < g.levels; level++) {  // tracker.cpp:32
+        TraceRange tr(kLevelName[level]);
         const bool lists = tile_margin == 0 && !single_launch[level];  // (k_track_gn_tile keeps the per-sequence active flag test)
         const size_t level_px = (size_t)g.w[level] * g.h[level];
         const int host_its = fused[level] ? 1 : max_it;  // a fused level iterates on the device (k_track_level)

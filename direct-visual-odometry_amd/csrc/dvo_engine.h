@@ -220,6 +220,13 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
 
 int select_device(int device);
 
+// Optional roctx ranges (the reference prints a Timer line per Gauss-Newton iteration and mapping stage: tracker.cpp:43,54-61,
+// mapper.cpp:18,27,32): with DVO_TRACE=1 in the environment every tracking level and mapping stage of a frame is a named range in a
+// `rocprofv3 --marker-trace` timeline.  libroctx64 is loaded lazily with dlopen; without it, or without DVO_TRACE, these are no-ops.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange { explicit TraceRange(const char* n) { trace_push(n); } ~TraceRange() { trace_pop(); } };
+
 // n_seq independent MONO sequences on one GPU: System::VisualOdometry::odometrize (system.hpp:44-74) -- track against the newest
 // keyframe, then Mapper::estimate (propagate + new keyframe, or stereo update) and regularize -- for every sequence per call, with
 // the keyframe decision taken on the device per sequence.  FrameHistory is a ring of the newest R keyframes per sequence

@@ -129,8 +129,9 @@ int MonoBatch::odometrize(const FrameInput& in)
         DVO_HIP(hipGetLastError());
         return DVO_OK;
     }
-    build_pyramid(frm, gin, stream);                                           // Frame(gray, K, 3, 2)
-    DVO_TRY(trk.track(frm, ref, stream));                                      // system.hpp:57
+    { TraceRange tr("mono pyramid"); build_pyramid(frm, gin, stream); }           // Frame(gray, K, 3, 2)
+    { TraceRange tr("mono track"); DVO_TRY(trk.track(frm, ref, stream)); }           // system.hpp:57
+    TraceRange tr_map("mono map (decide, propagate | update, promote, regularize)");
     launch_mono_decide(m, trk.state.as<SeqState>(), n_seq, frame_id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
                        xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), nullptr, stream);
     // ---- Mapper::estimate (mapper.cpp:16-33), both branches launched, each sequence takes its own ----
