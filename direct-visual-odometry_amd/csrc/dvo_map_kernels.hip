@@ -299,13 +299,21 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
     // rounded: its result can only differ from the exact root's side of `length` inside that band); inside the band the literal
     // test runs.  Same decisions, one fp64 sqrt per pixel instead of one per step.
     const double Ld = (double)length, L2 = Ld * Ld, L2lo = L2 * (1.0 - 1e-12), L2hi = L2 * (1.0 + 1e-12);
+    // ... and a float estimate of dx^2 + dy^2 (relative error < 2e-7) decides every step that is not within 1e-5 of the end of the
+    // segment without any fp64 instruction; the double test above only runs in that last sliver (and for NaN / overflow).
+    const float L2f = length * length, L2f_lo = L2f * (1.0f - 1e-5f), L2f_hi = L2f * (1.0f + 1e-5f);
     for (;;) {
         const float ddx = ptx - sx, ddy = pty - sy;
-        const double q2 = (double)ddx * (double)ddx + (double)ddy * (double)ddy;
+        const float q2f = fmaf(ddx, ddx, ddy * ddy);
         bool go;
-        if (q2 < L2lo) go = true;
-        else if (q2 > L2hi) go = false;
-        else go = sqrt(q2) < Ld;                  // (also the NaN case: every comparison above is false)
+        if (q2f < L2f_lo) go = true;
+        else if (q2f > L2f_hi) go = false;
+        else {
+            const double q2 = (double)ddx * (double)ddx + (double)ddy * (double)ddy;
+            if (q2 < L2lo) go = true;
+            else if (q2 > L2hi) go = false;
+            else go = sqrt(q2) < Ld;              // (also the NaN case: every comparison above is false)
+        }
         if (!go) break;
         float ssd = 0.0f;
         ptx += dirx;
