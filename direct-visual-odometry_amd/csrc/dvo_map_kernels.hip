@@ -247,11 +247,16 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // One reference pixel of Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214).  The per-keyframe
-// relative poses come from k_age_table (never a per-pixel exp/log).
-// KEY_ONLY: stop after the epipolar segment is known and return the number of search steps the pixel will take (0 = the pixel
-// leaves before the search: nothing to do); otherwise run the pixel to the end (return value unused).
-template <bool KEY_ONLY>
-__device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int seq, const int x, const int y)
+// relative poses come from k_age_table (never a per-pixel exp/log).  Split in a head (up to the epipolar segment, which fixes the
+// number of search steps) and a tail (the search and what follows), so that k_depth_update can reorder pixels between the two.
+struct UpdHead {   // what the head of the per-pixel computation hands to the search (kept in LDS between the two phases of k_depth_update)
+    float sx, sy, ex, ey, length, depth, sigma, dmin, dmax;
+    int qx, qy, bi;
+};
+
+// Head: mapper.cpp:90-107 + EpipolarSegment (implement.cpp:23-47).  Returns the number of search steps the pixel will take
+// (an upper bound within one step; 0 = the pixel leaves before the search: nothing to do).
+__device__ __forceinline__ int depth_update_head(const UpdateArgs& a, const int seq, const int x, const int y, UpdHead& hd)
 {
     const int w = a.w, h = a.h, npix = w * h;
     const MonoSeq* m = a.meta ? a.meta + seq : nullptr;
@@ -261,7 +266,6 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
     const float rel_tz = m ? m->rel_xi[2] : a.rel_tz;
     int n_hist = a.n_hist;
     if (m && a.ring_gray) n_hist = m->n_total < a.R ? m->n_total : a.R;
-    const int obj_id = m ? m->frame_id : a.obj_id;
     const float d = a.ref_depth[base + i];
     float pu, pv;
     warp(rel_pose, a.k, (float)x, (float)y, d, pu, pv);               // mapper.cpp:94
@@ -273,10 +277,8 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
     if (bi < 0 && a.clamp_age) bi = 0;
     if (bi < 0 || bi >= n_hist) return 0;
     const AgeEntry& born = a.ages[(size_t)seq * a.R + bi];
-    const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
     const float depth = d - rel_tz;                                    // mapper.cpp:104
     const float sigma = a.ref_sigma[base + i];
-    const GlobalImg bg{born_gray, w, h};
     // EpipolarSegment, implement.cpp:23-47
     const float dmin = (depth - sigma) < 0.10f ? 0.10f : (depth - sigma);
     const float dmax = depth + sigma;
@@ -285,10 +287,27 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
     warp(born.pose, a.k, (float)qx, (float)qy, dmin, ex, ey);
     const float sex = sx - ex, sey = sy - ey;
     const float length = (float)sqrt((double)sex * (double)sex + (double)sey * (double)sey);
-    if constexpr (KEY_ONLY) {   // steps of the loop below: it runs while |pt - start| < length, pt advancing one pixel per step, at most 102 times
-        if (!(length > 0.0f)) return 1;                       // (NaN or zero length: the loop test fails at once; the pixel still has its tail)
-        return length >= 102.0f ? 103 : (int)length + 2;      // an upper bound within one step is all the ordering needs
-    }
+    hd.sx = sx; hd.sy = sy; hd.ex = ex; hd.ey = ey; hd.length = length; hd.depth = depth; hd.sigma = sigma; hd.dmin = dmin; hd.dmax = dmax;
+    hd.qx = qx; hd.qy = qy; hd.bi = bi;
+    // steps of the search loop: it runs while |pt - start| < length, pt advancing one pixel per step, at most 102 times
+    if (!(length > 0.0f)) return 1;                       // (NaN or zero length: the loop test fails at once; the pixel still has its tail)
+    return length >= 102.0f ? 103 : (int)length + 2;
+}
+
+// Tail: doMatching, depthEstimate, sigmaEstimate and the fusion (implement.cpp:49-152,182-214, mapper.cpp:122-131) of one pixel.
+__device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int seq, const int x, const int y, const UpdHead& hd)
+{
+    const int w = a.w, h = a.h, npix = w * h;
+    const MonoSeq* m = a.meta ? a.meta + seq : nullptr;
+    const int i = y * w + x;
+    const size_t base = (size_t)seq * npix;
+    const int obj_id = m ? m->frame_id : a.obj_id;
+    const AgeEntry& born = a.ages[(size_t)seq * a.R + hd.bi];
+    const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
+    const GlobalImg bg{born_gray, w, h};
+    const float sx = hd.sx, sy = hd.sy, ex = hd.ex, ey = hd.ey, length = hd.length, depth = hd.depth, sigma = hd.sigma, dmin = hd.dmin, dmax = hd.dmax;
+    const int qx = hd.qx, qy = hd.qy;
+    const float sex = sx - ex, sey = sy - ey;
     // doMatching, implement.cpp:106-152
     const float og = a.obj_gray[base + qy * w + qx];
     const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
@@ -354,8 +373,8 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
         if (ssd < min_ssd) { bestx = ptx; besty = pty; min_ssd = ssd; }
         if (count++ > 100) break;
     }
-    if ((double)min_ssd > 3 * 0.1) return 0;                             // implement.cpp:145
-    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return 0;  // implement.cpp:196-200
+    if ((double)min_ssd > 3 * 0.1) return;                             // implement.cpp:145
+    if (bestx < 0.0f || besty < 0.0f || bestx > (float)w || besty > (float)h) return;  // implement.cpp:196-200
     // depthEstimate, implement.cpp:49-71 (double from float inputs)
     float nd;
     {
@@ -392,7 +411,7 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
         mx = mx < 0 ? 0 : (mx > w - 1 ? w - 1 : mx);  // D5 clamp
         my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
         const float gx = grad_x_at(bg, mx, my), gy = grad_y_at(bg, mx, my);
-        if (is_invalid(gx) || is_invalid(gy)) return 0;  // new_sigma = -1 fails the gate of mapper.cpp:122
+        if (is_invalid(gx) || is_invalid(gy)) return;  // new_sigma = -1 fails the gate of mapper.cpp:122
         const float gl = fabsf(fmaf(gy, ly, gx * lx));
         const float gl2 = gl * gl, gp2 = gl / l;
         const float epi = 0.25f / (gl2 < kEpsilon ? kEpsilon : gl2);
@@ -407,7 +426,6 @@ __device__ __forceinline__ int depth_update_pixel(const UpdateArgs& a, const int
         a.ref_depth[base + i] = gd;                                    // mapper.cpp:130-131
         a.ref_sigma[base + i] = gs;
     }
-    return 0;
 }
 
 // Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214): one thread per reference pixel of the
@@ -422,8 +440,10 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
 {
     __shared__ int bucket_cnt[128];     // pixels per step count, index 127 - steps (longest first)
     __shared__ int bucket_off[128];
-    __shared__ int order[256];
+    __shared__ int order[256];          // producer thread of the pixel each thread searches
     __shared__ int n_listed;
+    __shared__ float head_f[9][256];    // UpdHead of every listed pixel, by producer thread (the head is computed once)
+    __shared__ int head_i[3][256];
     const int w = a.w, h = a.h;
     // Only the window of mapper.cpp:90 (x in [16,144], y in [12,108]) is launched when the crop is on.
     const int x_lo = a.crop ? 16 : 0, y_lo = a.crop ? 12 : 0;
@@ -432,13 +452,21 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     int seq, j;
     const bool mine = seq_pixel(ww * wh, seq, j);       // (seq is block-uniform; only the last block of a sequence has idle threads)
     if (a.meta && a.ring_gray && a.meta[seq].need) return;   // this sequence created a keyframe instead (mapper.cpp:23-27); block-uniform
+    const int j0 = j - (int)threadIdx.x;                 // window index of this workgroup's first thread
     if (threadIdx.x < 128) bucket_cnt[threadIdx.x] = 0;
     __syncthreads();
     int steps = 0, rank = 0;
     if (mine) {
         const int wy = j / ww, wx = j - wy * ww;
-        steps = depth_update_pixel<true>(a, seq, x_lo + wx, y_lo + wy);
-        if (steps > 0) rank = atomicAdd(&bucket_cnt[127 - steps], 1);
+        UpdHead hd;
+        steps = depth_update_head(a, seq, x_lo + wx, y_lo + wy, hd);
+        if (steps > 0) {
+            rank = atomicAdd(&bucket_cnt[127 - steps], 1);
+            const int t = (int)threadIdx.x;
+            head_f[0][t] = hd.sx; head_f[1][t] = hd.sy; head_f[2][t] = hd.ex; head_f[3][t] = hd.ey; head_f[4][t] = hd.length;
+            head_f[5][t] = hd.depth; head_f[6][t] = hd.sigma; head_f[7][t] = hd.dmin; head_f[8][t] = hd.dmax;
+            head_i[0][t] = hd.qx; head_i[1][t] = hd.qy; head_i[2][t] = hd.bi;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {   // exclusive prefix sum over the 128 buckets, two per lane of wave 0
@@ -456,12 +484,17 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
         if (threadIdx.x == 63) n_listed = incl;
     }
     __syncthreads();
-    if (steps > 0) order[bucket_off[127 - steps] + rank] = j;
+    if (steps > 0) order[bucket_off[127 - steps] + rank] = (int)threadIdx.x;
     __syncthreads();
     if ((int)threadIdx.x < n_listed) {
-        const int jq = order[threadIdx.x];
+        const int p = order[threadIdx.x];
+        UpdHead hd;
+        hd.sx = head_f[0][p]; hd.sy = head_f[1][p]; hd.ex = head_f[2][p]; hd.ey = head_f[3][p]; hd.length = head_f[4][p];
+        hd.depth = head_f[5][p]; hd.sigma = head_f[6][p]; hd.dmin = head_f[7][p]; hd.dmax = head_f[8][p];
+        hd.qx = head_i[0][p]; hd.qy = head_i[1][p]; hd.bi = head_i[2][p];
+        const int jq = j0 + p;
         const int wy = jq / ww, wx = jq - wy * ww;
-        (void)depth_update_pixel<false>(a, seq, x_lo + wx, y_lo + wy);
+        depth_update_tail(a, seq, x_lo + wx, y_lo + wy, hd);
     }
 }
 
