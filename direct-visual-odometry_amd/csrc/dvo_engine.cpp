@@ -53,6 +53,17 @@ Roctx& roctx() { static Roctx r; return r; }
 void trace_push(const char* name) { if (roctx().push) (void)roctx().push(name); }
 void trace_pop() { if (roctx().pop) (void)roctx().pop(); }
 
+bool host_buffer_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();   // (an ordinary malloc'ed pointer is "invalid value" to HIP: not an error of ours)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 int select_device(int device)
 {
     int n = 0;
@@ -894,6 +905,10 @@ int Batch::push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1,
     if (p1) DVO_HIP(hipMemcpyAsync(st.b.p, p1, n1, hipMemcpyHostToDevice, cstream));
     if (p2) DVO_HIP(hipMemcpyAsync(st.c.p, p2, n2, hipMemcpyHostToDevice, cstream));
     DVO_HIP(hipEventRecord(st.copied, cstream));
+    // Pageable memory: the runtime may pin it in place and return while the DMA is still reading it, and the caller is free to
+    // release the buffer as soon as this call returns -- so wait for the copy (only the copy: the tracking of the previous frame
+    // keeps running on `stream`).  Pinned buffers stay asynchronous, as the header says.
+    if (!host_buffer_is_pinned(p0) || (p1 && !host_buffer_is_pinned(p1)) || (p2 && !host_buffer_is_pinned(p2))) DVO_HIP(hipStreamSynchronize(cstream));
     DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));
     if (in.raw()) { in.rgb = st.a.as<uint8_t>(); in.depth16 = st.b.as<uint16_t>(); }
     else { in.gray = st.a.as<float>(); in.depth = st.b.as<float>(); in.sigma = st.c.as<float>(); }

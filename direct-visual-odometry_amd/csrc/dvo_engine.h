@@ -219,6 +219,9 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
 };
 
 int select_device(int device);
+// true when `p` is page-locked host memory known to HIP (hipHostMalloc / hipHostRegister): only then may an asynchronous copy
+// still read the buffer after the call that queued it has returned
+bool host_buffer_is_pinned(const void* p);
 
 // Optional roctx ranges (the reference prints a Timer line per Gauss-Newton iteration and mapping stage: tracker.cpp:43,54-61,
 // mapper.cpp:18,27,32): with DVO_TRACE=1 in the environment every tracking level and mapping stage of a frame is a named range in a

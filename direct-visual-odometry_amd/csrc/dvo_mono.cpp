@@ -94,6 +94,7 @@ int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
     DVO_HIP(hipMemcpyAsync(st.buf.p, frames, bytes, hipMemcpyHostToDevice, cstream));
     DVO_HIP(hipEventRecord(st.copied, cstream));
+    if (!host_buffer_is_pinned(frames)) DVO_HIP(hipStreamSynchronize(cstream));   // pageable source: see Batch::push_host_frame
     DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));
     if (in.raw()) in.rgb = st.buf.as<uint8_t>(); else in.gray = st.buf.as<float>();
     const int rc = odometrize(in);

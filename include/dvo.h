@@ -138,7 +138,9 @@ int dvo_batch_push_device(dvo_batch* b, const float* gray_dev, const float* dept
 int dvo_batch_prefetch_device(dvo_batch* b, const float* gray_dev, const float* depth_dev, const float* sigma_dev);
 /* same, from host memory: the H2D copies run on a library-owned copy stream into one of two staging slots, so the transfer of
  * frame k+1 overlaps the tracking of frame k when the caller pushes without synchronising in between.  With PINNED host
- * buffers the copies are asynchronous: leave a buffer unchanged until a later dvo_batch_synchronize / dvo_batch_last_poses. */
+ * buffers (hipHostMalloc / hipHostRegister) the copies are asynchronous: leave a buffer unchanged until a later
+ * dvo_batch_synchronize / dvo_batch_last_poses.  A pageable buffer has been copied when the call returns (the call waits for the
+ * copy, not for the tracking) and may be reused or freed at once. */
 int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, const float* sigma);
 /* The same three calls fed with RAW sensor frames, [n_seq][height][width] u8 gray / R,G,B / R,G,B,A (channels 1 / 3 / 4) + u16
  * depth: what cv::imread delivers before Loader::getNormalizedImages converts it (src/core/loader.cpp:137-147).  The conversion

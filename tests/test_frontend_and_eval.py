@@ -306,6 +306,58 @@ def test_mono_batch_raw_equals_float():
     mb.close()
 
 
+@pytest.mark.gpu
+def test_pageable_host_buffers_may_be_reused_when_the_push_returns():
+    """include/dvo.h: a pageable buffer handed to dvo_batch_push_host / _push_raw_host / _odometrize_*_host has been copied when the
+    call returns (only pinned buffers stay in flight).  The caller here scribbles over its one set of buffers right after every push
+    -- what a capture loop that reuses its frame buffer does -- and must get the poses of a run that kept every frame untouched."""
+    from util import K640, frames
+    g, d, s, _ = frames(4, sigma=0.1)
+    B = 24                                                    # 3 x 29 MB per push: the DMA is still running when the call would return
+    def stacks(k):
+        return (np.stack([g[(k + b) % 4] for b in range(B)]), np.stack([d[(k + b) % 4] for b in range(B)]), np.stack([s[(k + b) % 4] for b in range(B)]))
+    def run(reuse):
+        bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        bufs = [np.empty((B, 480, 640), np.float32) for _ in range(3)]
+        keep, out = [], []
+        for k in range(4):
+            src = stacks(k)
+            if reuse:
+                for buf, a in zip(bufs, src):
+                    buf[...] = a
+                bt.push_host(*bufs)
+                for buf in bufs:
+                    buf[...] = -7.0                           # the frame is gone as far as the caller is concerned
+            else:
+                keep.append(src)
+                bt.push_host(*src)
+            if k > 0:
+                out.append(bt.last_poses()[0].copy())
+        bt.close()
+        return np.stack(out)
+    ref = run(False)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 1e-5
+    np.testing.assert_array_equal(run(True), ref)
+    # the mono batch's host entry point, raw u8 frames
+    def run_mono(reuse):
+        mb = dvo.MonoBatch(B, K640, 640, 480, cfg=dvo.default_config(rng_seed=2))
+        buf = np.empty((B, 480, 640), np.uint8)
+        keep, out = [], []
+        for k in range(4):
+            g8 = np.stack([np.clip(np.rint(g[(k + b) % 4] * 255), 0, 255).astype(np.uint8) for b in range(B)])
+            if reuse:
+                buf[...] = g8
+                mb.odometrize_host(buf)
+                buf[...] = 0
+            else:
+                keep.append(g8)
+                mb.odometrize_host(g8)
+            out.append(mb.world_poses()[1].copy())
+        mb.close()
+        return np.stack(out)
+    np.testing.assert_array_equal(run_mono(True), run_mono(False))
+
+
 # ---------------------------------------------------------------- whole-trajectory agreement (BASELINE.json: ATE within 1e-3 m of the reference)
 @pytest.mark.gpu
 def test_trajectory_ate_gpu_vs_oracle_on_synthetic_ground_truth():
