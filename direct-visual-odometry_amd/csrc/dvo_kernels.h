@@ -23,6 +23,7 @@ struct PyramidArgs {
     int src_w, src_h, culls, levels;
     int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS];
     float inv_tw;                      // 1 / top-level width
+    int n_seq = 0;                     // set by launch_pyramid
     // optional (iz[0] != nullptr, depth and sigma present): also write the k_prep_ref maps of every level
     float* iz[DVO_MAX_LEVELS];
     float* wgt[DVO_MAX_LEVELS];
@@ -36,6 +37,17 @@ struct PyramidArgs {
     int raw_channels, raw_invalidate_gray;
     float raw_gray_scale, raw_depth_scale, raw_sigma_valid, raw_sigma_invalid;
 };
+
+// Grids of the per-(sequence, pixel) kernels: x = workgroups of one sequence, (y, z) = the sequence -- seq = z * 32768 + y, so the
+// sequence index costs no division and is not capped by the 65 535 limit of one grid dimension.  Kernels return for seq >= n_seq.
+#define DVO_GRID_SEQ_Y 32768u
+#ifdef __HIPCC__
+inline dim3 seq_grid(unsigned blocks_per_seq, unsigned n_seq)
+{
+    const unsigned gy = n_seq < DVO_GRID_SEQ_Y ? (n_seq ? n_seq : 1u) : DVO_GRID_SEQ_Y;
+    return dim3(blocks_per_seq ? blocks_per_seq : 1u, gy, (n_seq + gy - 1u) / gy);
+}
+#endif
 
 struct GnArgs {
     const float* obj_gray;   // level buffers [n_seq][h][w]
@@ -186,6 +198,7 @@ struct UpdateArgs {
     const MonoSeq* meta;             // rel_pose, rel_xi[2], n_total, need, valid_updates per sequence; nullptr: the explicit fields
     int n_seq, R, n_hist, w, h, crop, obj_id;
     int clamp_age;           // bounded history: a pixel born in a dropped keyframe searches the oldest retained one
+    float inv_ww = 0.0f;     // 1 / width of the launched window (set by launch_depth_update)
     uint32_t seed;
     Intr k;
     float K9[9];
@@ -202,6 +215,7 @@ struct PropArgs {      // Implement::propagate (implement.cpp:217-256)
     Intr k;
     const MonoSeq* meta;     // per-sequence pose + need flag; nullptr: `pose` / `tz` below, unconditional
     Pose pose; float tz;
+    float inv_w = 0.0f;      // 1 / w (set by launch_propagate_batch)
 };
 
 #define DVO_PROMOTE_MAX_SEG 8
@@ -236,6 +250,7 @@ struct RegDecArgs {
     float* depth_lv[DVO_MAX_LEVELS]; float* sigma_lv[DVO_MAX_LEVELS]; float* iz[DVO_MAX_LEVELS]; float* wgt[DVO_MAX_LEVELS];  // per level (top: iz, wgt only)
     int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS], levels, n_seq;
     float step[DVO_MAX_LEVELS], sigma_min, sigma_max;
+    float inv_w = 0.0f;                       // 1 / top-level width (set by the launch wrapper)
 };
 void launch_regularize_redecimate(const RegDecArgs& a, hipStream_t s);
 

@@ -138,10 +138,9 @@ __device__ __forceinline__ void split_index(int i, int w, float inv_w, int& x, i
 __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
 {
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
-    const unsigned bps = ((unsigned)(tw * th) + 255u) >> 8;  // workgroups per sequence (the sequence index lives in grid.x: no 65535 limit)
-    const int seq = (int)(blockIdx.x / bps);
-    const int i = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + threadIdx.x;
-    if (i >= tw * th) return;
+    const int seq = (int)(blockIdx.z * DVO_GRID_SEQ_Y + blockIdx.y);   // seq_grid() (dvo_kernels.h): no division, no 65535 limit
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tw * th || seq >= a.n_seq) return;
     int x, y;
     split_index(i, tw, a.inv_tw, x, y);
     const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << a.culls) * a.src_w + (x << a.culls);
@@ -202,11 +201,12 @@ template <int CULLS>
 __global__ void __launch_bounds__(256) k_pyramid_raw4(PyramidArgs a)
 {
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1], gw = tw >> 2;
-    const unsigned bps = ((unsigned)(gw * th) + 255u) >> 8;
-    const int seq = (int)(blockIdx.x / bps);
-    const int gi = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + threadIdx.x;
-    if (gi >= gw * th) return;
-    const int y = gi / gw, x0 = (gi - y * gw) << 2;
+    const int seq = (int)(blockIdx.z * DVO_GRID_SEQ_Y + blockIdx.y);
+    const int gi = (int)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= gw * th || seq >= a.n_seq) return;
+    int y, xg;
+    split_index(gi, gw, a.inv_tw * 4.0f, xg, y);   // (4 / tw = 1 / gw up to an ulp: split_index corrects +-1)
+    const int x0 = xg << 2;
     const size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << CULLS) * a.src_w + ((size_t)x0 << CULLS);
     constexpr int GW = 1 << CULLS;       // 32-bit words of gray bytes this thread reads (2 or 4)
     unsigned gwords[GW], dwords[2 * GW];
@@ -1292,8 +1292,10 @@ void launch_undistort(const float* src, int w, int h, const Intr& k, const float
 
 static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s)
+void launch_pyramid(const PyramidArgs& a0, int n_seq, hipStream_t s)
 {
+    PyramidArgs a = a0;
+    a.n_seq = n_seq;
     const int tw = a.w[a.levels - 1], th = a.h[a.levels - 1];
     // raw 1-channel frames with the usual alignment: four kept pixels per thread, wide loads and stores
     const bool vec = a.raw_rgb != nullptr && a.raw_channels == 1 && (a.culls == 1 || a.culls == 2) && (tw % 4) == 0 && (a.src_w % (4 << a.culls)) == 0 &&
@@ -1306,12 +1308,12 @@ void launch_pyramid(const PyramidArgs& a, int n_seq, hipStream_t s)
         aligned = aligned && ((size_t)tw * th % 4) == 0;
     }
     if (vec && aligned) {
-        const dim3 grid(cdiv((tw >> 2) * th, 256) * (unsigned)n_seq);
+        const dim3 grid = seq_grid(cdiv((tw >> 2) * th, 256), (unsigned)n_seq);
         if (a.culls == 1) hipLaunchKernelGGL(k_pyramid_raw4<1>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_pyramid_raw4<2>, grid, dim3(256), 0, s, a);
         return;
     }
-    hipLaunchKernelGGL(k_pyramid, dim3(cdiv(tw * th, 256) * (unsigned)n_seq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pyramid, seq_grid(cdiv(tw * th, 256), (unsigned)n_seq), dim3(256), 0, s, a);
 }
 
 void launch_cull(const float* src, int w, int h, int times, float* dst, hipStream_t s)

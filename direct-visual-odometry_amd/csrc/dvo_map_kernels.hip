@@ -12,13 +12,23 @@ namespace dvo {
 
 static inline unsigned cdiv_u(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-// (sequence, pixel) of a thread; false when the thread has no pixel
-__device__ __forceinline__ bool seq_pixel(int npix, int& seq, int& i)
+// (sequence, pixel) of a thread; false when the thread has no pixel.  Grid = seq_grid() (dvo_kernels.h): the sequence is
+// (blockIdx.z, blockIdx.y), no division.
+__device__ __forceinline__ int grid_seq() { return (int)(blockIdx.z * DVO_GRID_SEQ_Y + blockIdx.y); }
+__device__ __forceinline__ bool seq_pixel(int npix, int n_seq, int& seq, int& i)
 {
-    const unsigned bps = ((unsigned)npix + 255u) >> 8;
-    seq = (int)(blockIdx.x / bps);
-    i = (int)(blockIdx.x - (unsigned)seq * bps) * 256 + (int)threadIdx.x;
-    return i < npix;
+    seq = grid_seq();
+    i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    return (i < npix) & (seq < n_seq);
+}
+// y = i / w, x = i % w for 0 <= i < 2^24 through the reciprocal (the +-1 fix-up is branch free)
+__device__ __forceinline__ void split_row(int i, int w, float inv_w, int& x, int& y)
+{
+    y = (int)((float)i * inv_w);
+    x = i - y * w;
+    const int lo = x < 0 ? 1 : 0, hi = x >= w ? 1 : 0;
+    y += hi - lo;
+    x += (lo - hi) * w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,18 +131,17 @@ __global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
 // (four pixels per thread: on most frames most sequences take the other branch, and a workgroup that only finds that out costs
 //  as much to dispatch as one that works -- a quarter of the workgroups)
 #define DVO_PROP_PER_THREAD 4
-__device__ __forceinline__ int prop_chunk(int npix, int& seq)   // first pixel of this thread (stride 256), sequence of the workgroup
+__device__ __forceinline__ int prop_chunk(int& seq)   // first pixel of this thread (stride 256), sequence of the workgroup
 {
-    const unsigned bps = ((unsigned)npix + 256u * DVO_PROP_PER_THREAD - 1u) / (256u * DVO_PROP_PER_THREAD);
-    seq = (int)(blockIdx.x / bps);
-    return (int)(blockIdx.x - (unsigned)seq * bps) * (256 * DVO_PROP_PER_THREAD) + (int)threadIdx.x;
+    seq = grid_seq();
+    return (int)blockIdx.x * (256 * DVO_PROP_PER_THREAD) + (int)threadIdx.x;
 }
 
 __global__ void __launch_bounds__(256) k_propagate_init(PropArgs a)
 {
     int seq;
-    const int n = a.w * a.h, i0 = prop_chunk(n, seq);
-    if (a.meta && !a.meta[seq].need) return;
+    const int n = a.w * a.h, i0 = prop_chunk(seq);
+    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
 #pragma unroll
     for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
         const int i = i0 + k * 256;
@@ -145,14 +154,15 @@ __global__ void __launch_bounds__(256) k_propagate_init(PropArgs a)
 __global__ void __launch_bounds__(256) k_propagate_owner(PropArgs a)
 {
     int seq;
-    const int w = a.w, h = a.h, n = w * h, i0 = prop_chunk(n, seq);
-    if (a.meta && !a.meta[seq].need) return;
+    const int w = a.w, h = a.h, n = w * h, i0 = prop_chunk(seq);
+    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
     const Pose pose = a.meta ? a.meta[seq].rel_pose : a.pose;   // wave-uniform
 #pragma unroll
     for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
         const int i = i0 + k * 256;
         if (i >= n) break;
-        const int y = i / w, x = i - y * w;
+        int x, y;
+        split_row(i, w, a.inv_w, x, y);
         const float rd = a.ref_depth[(size_t)seq * n + i];
         if (is_epsilon(rd)) continue;
         float pu, pv;
@@ -167,8 +177,8 @@ __global__ void __launch_bounds__(256) k_propagate_owner(PropArgs a)
 __global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
 {
     int seq;
-    const int n = a.w * a.h, o0 = prop_chunk(n, seq);
-    if (a.meta && !a.meta[seq].need) return;
+    const int n = a.w * a.h, o0 = prop_chunk(seq);
+    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
     const float tz = a.meta ? a.meta[seq].rel_xi[2] : a.tz;
     const size_t base = (size_t)seq * n;
 #pragma unroll
@@ -192,14 +202,15 @@ __global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
 
 // Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
 __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ depth_all, const float* __restrict__ sigma_all, int w, int h,
-                                                    float* __restrict__ out_all)
+                                                    int n_seq, float inv_w, float* __restrict__ out_all)
 {
     int seq, i;
-    if (!seq_pixel(w * h, seq, i)) return;
+    if (!seq_pixel(w * h, n_seq, seq, i)) return;
     const size_t base = (size_t)seq * w * h;
     const float* __restrict__ depth = depth_all + base;
     const float* __restrict__ sigma = sigma_all + base;
-    const int y = i / w, x = i - y * w;
+    int x, y;
+    split_row(i, w, inv_w, x, y);
     float gd = depth[i], gs = sigma[i];
     if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
     if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
@@ -216,11 +227,12 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
 {
     const int T = a.levels - 1, w = a.w[T], h = a.h[T];
     int seq, i;
-    if (!seq_pixel(w * h, seq, i)) return;
+    if (!seq_pixel(w * h, a.n_seq, seq, i)) return;
     const size_t base = (size_t)seq * w * h;
     const float* __restrict__ depth = a.depth + base;
     const float* __restrict__ sigma = a.sigma + base;
-    const int y = i / w, x = i - y * w;
+    int x, y;
+    split_row(i, w, a.inv_w, x, y);
     const float s0 = sigma[i];
     float gd = depth[i], gs = s0;
     if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
@@ -450,14 +462,16 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
     const int ww = a.crop ? (min(144, w - 1) - 16 + 1) : w, wh = a.crop ? (min(108, h - 1) - 12 + 1) : h;
     if (ww <= 0 || wh <= 0) return;
     int seq, j;
-    const bool mine = seq_pixel(ww * wh, seq, j);       // (seq is block-uniform; only the last block of a sequence has idle threads)
+    const bool mine = seq_pixel(ww * wh, a.n_seq, seq, j);       // (seq is block-uniform; only the last block of a sequence has idle threads)
+    if (seq >= a.n_seq) return;
     if (a.meta && a.ring_gray && a.meta[seq].need) return;   // this sequence created a keyframe instead (mapper.cpp:23-27); block-uniform
     const int j0 = j - (int)threadIdx.x;                 // window index of this workgroup's first thread
     if (threadIdx.x < 128) bucket_cnt[threadIdx.x] = 0;
     __syncthreads();
     int steps = 0, rank = 0;
     if (mine) {
-        const int wy = j / ww, wx = j - wy * ww;
+        int wx, wy;
+        split_row(j, ww, a.inv_ww, wx, wy);
         UpdHead hd;
         steps = depth_update_head(a, seq, x_lo + wx, y_lo + wy, hd);
         if (steps > 0) {
@@ -493,7 +507,8 @@ __global__ void __launch_bounds__(256) k_depth_update(UpdateArgs a)
         hd.depth = head_f[5][p]; hd.sigma = head_f[6][p]; hd.dmin = head_f[7][p]; hd.dmax = head_f[8][p];
         hd.qx = head_i[0][p]; hd.qy = head_i[1][p]; hd.bi = head_i[2][p];
         const int jq = j0 + p;
-        const int wy = jq / ww, wx = jq - wy * ww;
+        int wx, wy;
+        split_row(jq, ww, a.inv_ww, wx, wy);
         depth_update_tail(a, seq, x_lo + wx, y_lo + wy, hd);
     }
 }
@@ -514,12 +529,12 @@ __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
     total /= VEC;        // in units of VEC floats
     // 2048 units per workgroup: most sequences do not create a keyframe on a given frame, and a workgroup that only finds that
     // out costs as much to dispatch as one that copies -- fewer, fatter workgroups
-    const unsigned bps = ((unsigned)total + 256u * DVO_PROMOTE_PER_THREAD - 1u) / (256u * DVO_PROMOTE_PER_THREAD);
-    const int seq = (int)(blockIdx.x / bps);
+    const int seq = grid_seq();
+    if (seq >= a.n_seq) return;
     const MonoSeq& m = a.meta[seq];
     if (!a.all && !m.need) return;
     const int slot = a.all ? 0 : m.n_total % a.R;   // (k_mono_commit increments n_total AFTER this kernel)
-    const int i0 = (int)(blockIdx.x - (unsigned)seq * bps) * (256 * DVO_PROMOTE_PER_THREAD) + (int)threadIdx.x;
+    const int i0 = (int)blockIdx.x * (256 * DVO_PROMOTE_PER_THREAD) + (int)threadIdx.x;
 #pragma unroll
     for (int k = 0; k < DVO_PROMOTE_PER_THREAD; k++) {
         int i = i0 + k * 256;
@@ -542,10 +557,10 @@ __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src, float* __restrict__ dst, int count)
+__global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src, float* __restrict__ dst, int count, int n_seq)
 {
     int seq, i;
-    if (!seq_pixel(count, seq, i)) return;
+    if (!seq_pixel(count, n_seq, seq, i)) return;
     dst[(size_t)seq * count + i] = src[i];
 }
 
@@ -578,18 +593,20 @@ void launch_promote(const PromoteArgs& a, hipStream_t s)
         total += a.count[g];
         vec = vec && (a.count[g] % 4) == 0 && (reinterpret_cast<uintptr_t>(a.src[g]) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.dst[g]) % 16) == 0;
     }
-    if (vec) hipLaunchKernelGGL(k_promote<4>, dim3(cdiv_u(total / 4, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_promote<1>, dim3(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    if (vec) hipLaunchKernelGGL(k_promote<4>, seq_grid(cdiv_u(total / 4, 256 * DVO_PROMOTE_PER_THREAD), (unsigned)a.n_seq), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_promote<1>, seq_grid(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD), (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_broadcast, dim3(cdiv_u(count, 256) * (unsigned)n_seq), dim3(256), 0, s, src, dst, count);
+    hipLaunchKernelGGL(k_broadcast, seq_grid(cdiv_u(count, 256), (unsigned)n_seq), dim3(256), 0, s, src, dst, count, n_seq);
 }
 
-void launch_propagate_batch(const PropArgs& a, hipStream_t s)
+void launch_propagate_batch(const PropArgs& a0, hipStream_t s)
 {
-    const dim3 grid(cdiv_u(a.w * a.h, 256 * DVO_PROP_PER_THREAD) * (unsigned)a.n_seq);
+    PropArgs a = a0;
+    a.inv_w = 1.0f / (float)a.w;
+    const dim3 grid = seq_grid(cdiv_u(a.w * a.h, 256 * DVO_PROP_PER_THREAD), (unsigned)a.n_seq);
     hipLaunchKernelGGL(k_propagate_init, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_owner, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_pull, grid, dim3(256), 0, s, a);
@@ -607,13 +624,15 @@ void launch_propagate(const float* ref_depth, const float* ref_sigma, const floa
 
 void launch_regularize_batch(const float* depth, const float* sigma, int w, int h, int n_seq, float* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_regularize, dim3(cdiv_u(w * h, 256) * (unsigned)n_seq), dim3(256), 0, s, depth, sigma, w, h, out);
+    hipLaunchKernelGGL(k_regularize, seq_grid(cdiv_u(w * h, 256), (unsigned)n_seq), dim3(256), 0, s, depth, sigma, w, h, n_seq, 1.0f / (float)w, out);
 }
 
-void launch_regularize_redecimate(const RegDecArgs& a, hipStream_t s)
+void launch_regularize_redecimate(const RegDecArgs& a0, hipStream_t s)
 {
+    RegDecArgs a = a0;
     const int T = a.levels - 1;
-    hipLaunchKernelGGL(k_regularize_redecimate, dim3(cdiv_u(a.w[T] * a.h[T], 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    a.inv_w = 1.0f / (float)a.w[T];
+    hipLaunchKernelGGL(k_regularize_redecimate, seq_grid(cdiv_u(a.w[T] * a.h[T], 256), (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 void launch_regularize(const float* depth, const float* sigma, int w, int h, float* out, hipStream_t s)
@@ -621,11 +640,13 @@ void launch_regularize(const float* depth, const float* sigma, int w, int h, flo
     launch_regularize_batch(depth, sigma, w, h, 1, out, s);
 }
 
-void launch_depth_update(const UpdateArgs& a, hipStream_t s)
+void launch_depth_update(const UpdateArgs& a0, hipStream_t s)
 {
+    UpdateArgs a = a0;
     const int ww = a.crop ? ((a.w - 1 < 144 ? a.w - 1 : 144) - 16 + 1) : a.w, wh = a.crop ? ((a.h - 1 < 108 ? a.h - 1 : 108) - 12 + 1) : a.h;
     if (ww <= 0 || wh <= 0) return;
-    hipLaunchKernelGGL(k_depth_update, dim3(cdiv_u(ww * wh, 256) * (unsigned)a.n_seq), dim3(256), 0, s, a);
+    a.inv_ww = 1.0f / (float)ww;
+    hipLaunchKernelGGL(k_depth_update, seq_grid(cdiv_u(ww * wh, 256), (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 
 }  // namespace dvo

@@ -181,6 +181,26 @@ int main() {
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_gauss_gain_shortcut_matches_the_division():
+    """gauss_gain() (csrc/dvo_math.h) replaces the reference's m / 0.8f (gaussian.cpp:20) by a multiply and one residual step.
+    tools/verify/gauss_gain_div.c walks float bit patterns and compares the resulting gains bit for bit (all 2^32 when run by hand;
+    every 5th here), and dvo_math.h must still contain the constants the program checks."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    math_h = open(os.path.join(ROOT, "direct-visual-odometry_amd", "csrc", "dvo_math.h")).read()
+    assert "q0 = m * 1.25f" in math_h and "fmaf(fmaf(-q0, 0.8f, m), 1.25f, q0)" in math_h and "fabsf(m) < 1e30f" in math_h
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "ggd")
+        subprocess.run([gcc, "-O2", "-fopenmp", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "verify", "gauss_gain_div.c"), "-lm"],
+                       check=True, capture_output=True, timeout=300)
+        r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 gains differ, 0 quotients differ" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_code_is_clean_under_address_and_undefined_sanitizers():
     """the oracle's whole path and the host-only translation units of libdvo (PNG / dataset front-end with a
     mutation fuzz and crafted headers, trajectory evaluation) run once under -fsanitize=address,undefined.  GPU ASan does
