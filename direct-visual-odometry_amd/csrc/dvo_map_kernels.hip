@@ -200,6 +200,22 @@ __global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
     }
 }
 
+// The four neighbour fusions of Implement::regularize (implement.cpp:166-177), order L, R, D, U.  All eight neighbour loads are
+// issued before the first fusion (from the centre's address where a neighbour does not exist; that value is not used): the fusions
+// are a dependent chain, and with each load inside its own `if` the kernel paid four exposed memory round trips per pixel.
+__device__ __forceinline__ void regularize_fuse4(const float* __restrict__ depth, const float* __restrict__ sigma, int i, int x, int y, int w, int h,
+                                                 float& gd, float& gs)
+{
+    const bool hasL = x - 1 >= 0, hasR = x + 1 < w, hasD = y + 1 < h, hasU = y - 1 >= 0;
+    const int iL = hasL ? i - 1 : i, iR = hasR ? i + 1 : i, iD = hasD ? i + w : i, iU = hasU ? i - w : i;
+    const float dL = depth[iL], sL = sigma[iL], dR = depth[iR], sR = sigma[iR];
+    const float dD = depth[iD], sD = sigma[iD], dU = depth[iU], sU = sigma[iU];
+    if (hasL) gaussian_fuse(gd, gs, dL, sL);
+    if (hasR) gaussian_fuse(gd, gs, dR, sR);
+    if (hasD) gaussian_fuse(gd, gs, dD, sD);
+    if (hasU) gaussian_fuse(gd, gs, dU, sU);
+}
+
 // Implement::regularize (implement.cpp:156-180): reads the old maps, fuses L, R, D, U in that order.
 __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ depth_all, const float* __restrict__ sigma_all, int w, int h,
                                                     int n_seq, float inv_w, float* __restrict__ out_all)
@@ -212,10 +228,7 @@ __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ de
     int x, y;
     split_row(i, w, inv_w, x, y);
     float gd = depth[i], gs = sigma[i];
-    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
-    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
-    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
-    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
+    regularize_fuse4(depth, sigma, i, x, y, w, h, gd, gs);
     out_all[base + i] = gd < 6.0f ? gd : 6.0f;
 }
 
@@ -235,10 +248,7 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
     split_row(i, w, a.inv_w, x, y);
     const float s0 = sigma[i];
     float gd = depth[i], gs = s0;
-    if (x - 1 >= 0) gaussian_fuse(gd, gs, depth[i - 1], sigma[i - 1]);
-    if (x + 1 < w) gaussian_fuse(gd, gs, depth[i + 1], sigma[i + 1]);
-    if (y + 1 < h) gaussian_fuse(gd, gs, depth[i + w], sigma[i + w]);
-    if (y - 1 >= 0) gaussian_fuse(gd, gs, depth[i - w], sigma[i - w]);
+    regularize_fuse4(depth, sigma, i, x, y, w, h, gd, gs);
     const float nd = gd < 6.0f ? gd : 6.0f;                       // implement.cpp:178
     a.depth_top_out[base + i] = nd;                               // top level: the map itself (cullImage(src, 0) aliases, convert.cpp:9-10)
     __builtin_nontemporal_store(1.0f / nd, a.iz[T] + base + i);
