@@ -263,6 +263,7 @@ int dvo_dataset_size(const dvo_dataset* d) { return d ? (int)d->impl.e.size() : 
 int dvo_dataset_entry(const dvo_dataset* d, int i, double* timestamp, char* rgb_path, char* depth_path, int path_capacity, float gt_pose7[7])
 {
     if (!d || i < 0 || i >= (int)d->impl.e.size()) return DVO_ERR_BAD_ARGUMENT;
+    if ((rgb_path || depth_path) && path_capacity <= 0) return DVO_ERR_BAD_ARGUMENT;
     const DatasetEntry& e = d->impl.e[i];
     if (timestamp) *timestamp = e.t;
     if (rgb_path) snprintf(rgb_path, (size_t)path_capacity, "%s", e.rgb.c_str());
