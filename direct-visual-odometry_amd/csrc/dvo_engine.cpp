@@ -121,8 +121,8 @@ int make_geometry(const float K[9], int w, int h, int levels, int culls, Geometr
     for (int i = 0; i < levels; i++) {
         const int t = levels - 1 - i;  // frame.cpp:33-35
         g.w[i] = bw >> t; g.h[i] = bh >> t;
-        if (g.w[i] < 1 || g.h[i] < 1) {
-            set_error("image too small for this many pyramid levels");
+        if (g.w[i] < 4 || g.h[i] < 4) {  // k_track_gn's lanes without an interior position gather around (1, 1): rows / columns 0..3
+            set_error("image too small for this many pyramid levels (every level must be at least 4 x 4)");
             return DVO_ERR_BAD_ARGUMENT;
         }
         if ((size_t)g.w[i] * g.h[i] >= (1u << 24)) {

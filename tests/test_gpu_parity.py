@@ -540,3 +540,18 @@ def test_narrow_2d_tiles_parity(w, h):
     xg, lg = dvo.track(g[1], g[0], d[0], s[0], K, 2, 0, cfg=cfg)
     assert lg["n_iter"][:2] == [3, 3] == lo["n_iter"]
     np.testing.assert_allclose(xg, xo, rtol=0, atol=5e-5)
+
+
+def test_levels_smaller_than_4x4_are_refused():
+    """k_track_gn gathers a 4 x 4 neighbourhood around (1, 1) for lanes without an interior position, so a pyramid level below
+    4 x 4 would read outside its image: make_geometry refuses such a pyramid with a status code (never a fault)."""
+    K = np.array(K640, np.float32)
+    with pytest.raises(dvo.DvoError):
+        dvo.VisualOdometry(K, 24, 12)                      # mono geometry (3 levels, 2 culls): 6 x 3 -> 3 x 1 -> 1 x 0
+    with pytest.raises(dvo.DvoError):
+        dvo.Batch(2, K, 40, 24, levels=4, culls=1)         # 20 x 12 -> ... -> 2 x 1
+    g = np.full((3, 9), 0.5, np.float32)
+    with pytest.raises(dvo.DvoError):
+        dvo.optimize(g, g, g + 1.0, g, K, np.zeros(6, np.float32), 0)
+    bt = dvo.Batch(2, K, 64, 32, levels=4, culls=0)        # coarsest level 8 x 4: the smallest that is accepted
+    bt.close()
