@@ -269,7 +269,7 @@ def main():
 
     # ---- PCIe-inclusive rate (reported in config, never `value`): the same steps fed from pinned HOST buffers ----
     if a.pcie_steps > 0:
-        PB = min(B, 256)  # a bounded sample of the batch: the rate is PCIe bound, pinned host copies of everything are not needed
+        PB = min(B, 1024)  # a bounded sample of the batch: the rate is PCIe bound, pinned host copies of everything are not needed
         # (fixed launch schedule: the adaptive one keeps the host inside push() until the GPU is nearly done with the step, so the
         #  next frame's transfer would not be queued in time to overlap it)
         hcfg = dvo.default_config(device=local, stream=stream, fixed_iterations=a.fixed_iters, track_streams=a.streams, track_adaptive=-1,
@@ -299,7 +299,10 @@ def main():
         incl = PB * a.pcie_steps / (time.perf_counter() - t1)
         # co-headline (SURVEY.md §8d defines fps "including H2D of each gray frame and D2H of each pose"); `value` is HBM-resident
         out["value_incl_h2d"] = incl
+        full_frames = os.environ.get("DVO_UPLOAD_FULL_FRAMES") is not None
         out["incl_h2d"] = {"sequences": PB, "frames_streamed_per_sequence": a.pcie_steps, "bytes_per_frame": (3 if raw else 12) * W * H,
+                           "bytes_over_pcie_per_frame": (3 * W * (H >> culls if (culls > 0 and H % (1 << culls) == 0 and not full_frames) else H)) if raw else 12 * W * H,
+                           "note": "raw host frames: only the rows the pyramid keeps (every 2^culls-th: Convert::cullImage) are transferred, by one strided copy per buffer",
                            "input": ("pinned host u8 gray + u16 depth (dvo_batch_push_raw_host)" if raw else
                                      "pinned host float32 gray + depth + sigma (dvo_batch_push_host)") + ", every pose copied back to pinned host memory per step; "
                                     "transfers of step k+1 overlap the tracking of step k (copy stream, two staging slots)"}
@@ -571,7 +574,10 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
         hb.synchronize()
         torch.cuda.synchronize()
         out["value_incl_h2d"] = PB * a.pcie_steps / (time.perf_counter() - t1)
+        full_frames = os.environ.get("DVO_UPLOAD_FULL_FRAMES") is not None
         out["incl_h2d"] = {"sequences": PB, "frames_streamed_per_sequence": a.pcie_steps, "bytes_per_frame": (1 if raw else 4) * W * H,
+                           "bytes_over_pcie_per_frame": (W * (H >> 2 if (H % 4 == 0 and not full_frames) else H)) if raw else 4 * W * H,
+                           "note": "raw host frames: only the rows the pyramid keeps (every 4th: Frame(gray,K,3,2)) are transferred, by one strided copy",
                            "input": "pinned host %s gray (dvo_batch_odometrize_%shost), every world pose copied back per step" % (("u8", "raw_") if raw else ("float32", ""))}
         hb.close()
     if not a.no_roofline:

@@ -211,6 +211,8 @@ void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_
     a.raw_gray_scale = (float)(1.0 / 255.0); a.raw_depth_scale = in.depth_scale;
     a.raw_sigma_valid = 0.1f; a.raw_sigma_invalid = 1.0f; a.raw_invalidate_gray = 1;   // transform.cpp:60-76
     a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
+    a.raw_img_rows = in.rows_decimated ? fs.g.src_h >> fs.g.culls : fs.g.src_h;
+    a.raw_row_shift = in.rows_decimated ? 0 : fs.g.culls;
     const bool dep = in.depth16 != nullptr;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
@@ -221,6 +223,23 @@ void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
     if (dep) fuse_prep(a, fs);
     launch_pyramid(a, fs.n_seq, s);
+}
+
+int upload_raw_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
+                    size_t* stored)
+{
+    if (!decimate || culls <= 0) {
+        const size_t n = row_bytes * (size_t)img_rows * n_img;
+        if (stored) *stored = n;
+        DVO_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
+        return DVO_OK;
+    }
+    // img_rows is a multiple of 2^culls (can_decimate_rows), so the kept rows of ALL images are the rows r = 0 (mod 2^culls) of the
+    // n_img * img_rows rows of the whole buffer: one 2-D copy with a source pitch of 2^culls rows
+    const size_t rows = ((size_t)img_rows >> culls) * n_img;
+    if (stored) *stored = row_bytes * rows;
+    DVO_HIP(hipMemcpy2DAsync(dst, row_bytes, src, row_bytes << culls, row_bytes, rows, hipMemcpyHostToDevice, s));
+    return DVO_OK;
 }
 
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s)
@@ -719,7 +738,8 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     if (raw) {
         const size_t px = (size_t)w * h;
         if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
-        DVO_HIP(hipMemcpyAsync(raw_rgb.p, raw, px * (size_t)raw_channels, hipMemcpyHostToDevice, stream));
+        fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps cross PCIe
+        DVO_TRY(upload_raw_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
         fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
     } else {
         DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -802,9 +822,10 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     DVO_TRY(select_device(device));
     const size_t px = (size_t)w * h;
     if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
-    DVO_HIP(hipMemcpyAsync(raw_rgb.p, rgb, px * (size_t)channels, hipMemcpyHostToDevice, stream));
-    DVO_HIP(hipMemcpyAsync(raw_depth.p, depth16, px * 2, hipMemcpyHostToDevice, stream));
     FrameInput in;
+    in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);   // only the rows the pyramid keeps cross PCIe
+    DVO_TRY(upload_raw_rows(raw_rgb.p, rgb, (size_t)w * channels, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_TRY(upload_raw_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
     in.rgb = raw_rgb.as<uint8_t>(); in.channels = channels; in.depth16 = raw_depth.as<uint16_t>(); in.depth_scale = depth_scale;
     return odometrize_depth_staged(T_rel, &in);
 }
@@ -901,9 +922,15 @@ int Batch::push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1,
     if (p1 && st.b.bytes < n1) DVO_TRY(st.b.alloc(n1));
     if (p2 && st.c.bytes < n2) DVO_TRY(st.c.alloc(n2));
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
-    DVO_HIP(hipMemcpyAsync(st.a.p, p0, n0, hipMemcpyHostToDevice, cstream));
-    if (p1) DVO_HIP(hipMemcpyAsync(st.b.p, p1, n1, hipMemcpyHostToDevice, cstream));
-    if (p2) DVO_HIP(hipMemcpyAsync(st.c.p, p2, n2, hipMemcpyHostToDevice, cstream));
+    if (in.raw()) {  // only the rows the pyramid keeps cross PCIe (the staging buffers are sized for whole frames)
+        in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
+        DVO_TRY(upload_raw_rows(st.a.p, p0, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        DVO_TRY(upload_raw_rows(st.b.p, p1, (size_t)g.src_w * 2, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+    } else {
+        DVO_HIP(hipMemcpyAsync(st.a.p, p0, n0, hipMemcpyHostToDevice, cstream));
+        if (p1) DVO_HIP(hipMemcpyAsync(st.b.p, p1, n1, hipMemcpyHostToDevice, cstream));
+        if (p2) DVO_HIP(hipMemcpyAsync(st.c.p, p2, n2, hipMemcpyHostToDevice, cstream));
+    }
     DVO_HIP(hipEventRecord(st.copied, cstream));
     // Pageable memory: the runtime may pin it in place and return while the DMA is still reading it, and the caller is free to
     // release the buffer as soon as this call returns -- so wait for the copy (only the copy: the tracking of the previous frame

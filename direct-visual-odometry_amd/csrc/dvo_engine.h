@@ -6,6 +6,7 @@
 //   System::VisualOdometry -> VisualOdometry                                           include/system/system.hpp
 // There is NO CPU fallback: every entry point fails with DVO_ERR_NO_DEVICE / DVO_ERR_HIP without a GPU.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 
 #include <memory>
@@ -77,12 +78,20 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
 struct FrameInput {
     const float* gray = nullptr; const float* depth = nullptr; const float* sigma = nullptr;
     const uint8_t* rgb = nullptr; int channels = 0; const uint16_t* depth16 = nullptr; float depth_scale = 1.0f / 5000.0f;
+    bool rows_decimated = false;  // raw buffers hold only the rows the pyramid keeps (every 2^culls-th), see Batch::push_host_frame
     bool raw() const { return rgb != nullptr; }
     const void* key0() const { return raw() ? (const void*)rgb : (const void*)gray; }
     const void* key1() const { return raw() ? (const void*)depth16 : (const void*)depth; }
     bool has_depth() const { return raw() ? depth16 != nullptr : (depth != nullptr && sigma != nullptr); }
 };
 void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_sigma = true);
+// Host -> device copy of raw frames of n_img images (rows of row_bytes bytes).  With culls > 0 and decimate set only every
+// 2^culls-th row of each image is transferred (one strided DMA): the pyramid never reads the others (Convert::cullImage keeps
+// pixels whose coordinates are multiples of 2^culls), so 1 - 2^-culls of the PCIe traffic carries nothing.  Returns the bytes
+// the device buffer holds through *stored.
+int upload_raw_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
+                    size_t* stored);
+inline bool can_decimate_rows(const Geometry& g) { return g.culls > 0 && (g.src_h % (1 << g.culls)) == 0; }
 // Frame::updateDepthSigma / updateDepth (frame.cpp:39-61): re-decimate from a top-level map (may alias the top level)
 void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hipStream_t s);
 
@@ -172,6 +181,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16]);
     int odometrize_depth_staged(float T_rel[16], const struct FrameInput* raw = nullptr);  // frame already staged on the device
     DevBuf raw_rgb, raw_depth;
+    bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // as Batch::decimate_host_rows
     int init_keyframe(const float* gray, const float* depth, const float* sigma);
     int map_propagate(Keyframe& frame, const Keyframe& ref);
     int map_update(Keyframe& obj);
@@ -205,6 +215,7 @@ struct Batch {  // n_seq independent sequences, frame-to-frame tracking with sen
     struct Stage { DevBuf a, b, c; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; } stage[2];
     hipStream_t cstream = nullptr;
     int n_host_push = 0;
+    bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // raw host frames: transfer only the rows the pyramid keeps
     int push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2, FrameInput in);
     ~Batch();
     int init(int n, const float K9[9], int w, int h, int levels, int culls, const dvo_config* c);
@@ -257,6 +268,7 @@ struct MonoBatch {
     struct Stage { DevBuf buf; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; } stage[2];
     hipStream_t cstream = nullptr;
     int n_host = 0;
+    bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // as Batch::decimate_host_rows
     int top_pixels() const { return g.w[g.top()] * g.h[g.top()]; }
 };
 

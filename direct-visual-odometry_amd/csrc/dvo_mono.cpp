@@ -92,7 +92,12 @@ int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
     n_host++;
     if (st.buf.bytes < bytes) DVO_TRY(st.buf.alloc(bytes));
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
-    DVO_HIP(hipMemcpyAsync(st.buf.p, frames, bytes, hipMemcpyHostToDevice, cstream));
+    if (in.raw()) {  // only the rows the pyramid keeps cross PCIe (Batch::push_host_frame)
+        in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
+        DVO_TRY(upload_raw_rows(st.buf.p, frames, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+    } else {
+        DVO_HIP(hipMemcpyAsync(st.buf.p, frames, bytes, hipMemcpyHostToDevice, cstream));
+    }
     DVO_HIP(hipEventRecord(st.copied, cstream));
     if (!host_buffer_is_pinned(frames)) DVO_HIP(hipStreamSynchronize(cstream));   // pageable source: see Batch::push_host_frame
     DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));

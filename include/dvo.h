@@ -146,7 +146,10 @@ int dvo_batch_push_host(dvo_batch* b, const float* gray, const float* depth, con
  * depth: what cv::imread delivers before Loader::getNormalizedImages converts it (src/core/loader.cpp:137-147).  The conversion
  * (BGR2GRAY fixed-point luma, 1/255, depth * depth_scale [0 = 1/5000], sigma 0.1 / 1.0 and INVALID gray where depth == 0:
  * src/core/transform.cpp:60-76) runs inside the pyramid kernel on the pixels the pyramid keeps: 3 B/px (gray) instead of 12 B/px
- * cross PCIe and are read from HBM, and the results are bit-identical to dvo_op_ingest + the float entry points. */
+ * cross PCIe and are read from HBM, and the results are bit-identical to dvo_op_ingest + the float entry points.  The HOST forms
+ * (here, dvo_batch_odometrize_raw_host, dvo_vo_odometrize_raw, dvo_vo_odometrize_depth_raw) transfer only the image rows the pyramid
+ * keeps -- every 2^culls-th, Convert::cullImage (src/core/convert.cpp:7-20) -- by one strided copy per buffer: half of the bytes
+ * for Frame(g,d,s,K,4,1), a quarter for Frame(gray,K,3,2).  DVO_UPLOAD_FULL_FRAMES=1 in the environment restores whole frames. */
 int dvo_batch_push_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale);
 int dvo_batch_prefetch_raw_device(dvo_batch* b, const uint8_t* rgb_dev, int channels, const uint16_t* depth16_dev, float depth_scale);
 int dvo_batch_push_raw_host(dvo_batch* b, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale);

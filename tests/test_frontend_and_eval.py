@@ -233,7 +233,12 @@ def test_batch_raw_push_equals_float_push(channels):
             rr.append(rgb); dd.append(d16); ff.append(dvo.ingest(rgb, d16))
         raw_rgb.append(np.stack(rr)); raw_d16.append(np.stack(dd)); fl.append(ff)
     def run(mode):
-        bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        if mode == "host_full":   # whole frames over PCIe (the default transfers only the rows the pyramid keeps: one strided copy)
+            os.environ["DVO_UPLOAD_FULL_FRAMES"] = "1"
+        try:
+            bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        finally:
+            os.environ.pop("DVO_UPLOAD_FULL_FRAMES", None)
         out = []
         if mode == "device":
             dev = torch.device("cuda", 0)
@@ -242,7 +247,7 @@ def test_batch_raw_push_equals_float_push(channels):
         for k in range(4):
             if mode == "float":
                 bt.push_host(np.stack([f[0] for f in fl[k]]), np.stack([f[1] for f in fl[k]]), np.stack([f[2] for f in fl[k]]))
-            elif mode == "host":
+            elif mode in ("host", "host_full"):
                 bt.push_raw_host(raw_rgb[k], raw_d16[k])
             else:
                 if 1 <= k < 3:
@@ -254,7 +259,7 @@ def test_batch_raw_push_equals_float_push(channels):
         return out
     ref = run("float")
     assert np.abs(ref[0][0]).max() > 1e-5
-    for mode in ("host", "device"):
+    for mode in ("host", "host_full", "device"):
         got = run(mode)
         for (xa, la), (xb, lb) in zip(ref, got):
             np.testing.assert_array_equal(xa, xb)
