@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="sub-batches tracked on concurrent HIP streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-prefetch", action="store_true", help="build every pyramid in order on the tracking stream")
+    ap.add_argument("--prefetch", action="store_true", help="build the pyramid of frame k+1 on the library's low-priority side stream while frame k "
+                    "tracks (dvo_batch_prefetch_*): +1 % frames/s, but k_track_gn then shares the chip with k_pyramid and its per-launch "
+                    "time -- the roofline figure -- reads 7 % longer; default: every pyramid in order on the tracking stream")
+    ap.add_argument("--no-prefetch", action="store_true", help="(the default since round 2; kept for old command lines)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-stream side measurements")
     ap.add_argument("--pcie-steps", type=int, default=8, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     return ap.parse_args()
@@ -175,11 +178,12 @@ def main():
     poses_out = torch.zeros((a.steps, B, 6), dtype=torch.float32, device=dev)
 
     def push(bt, k, out=None):
-        # frames are resident and complete: the pyramid of frame k+1 is built on the library's side stream while frame k tracks
-        # (dvo_batch_prefetch_device; --no-prefetch restores the strictly in-order form).  Every step from k = 1 on prefetches
-        # exactly one frame and consumes the one prefetched by the step before, so the K timed steps contain K pyramid builds.
+        # frames are resident and complete.  Default: each push builds its pyramid on the tracking stream.  --prefetch: the pyramid of
+        # frame k+1 is built on the library's side stream while frame k tracks (dvo_batch_prefetch_device); every step from k = 1 on
+        # then prefetches exactly one frame and consumes the one prefetched by the step before.  Either way K timed steps contain K
+        # pyramid builds.
         f = ring_index(k, F)
-        if not a.no_prefetch and k >= 1:
+        if a.prefetch and k >= 1:
             fn = ring_index(k + 1, F)
             if raw:
                 bt.prefetch_raw_device(gray8[fn].data_ptr(), 1, depth16[fn].data_ptr())
@@ -236,6 +240,9 @@ def main():
                    if a.workload == "syn640" else "SYN-1080 dense alignment, 5-level pyramid, fixed iterations",
                    "input": "raw u8 gray + u16 depth (3 B/px), converted inside k_pyramid" if raw else "float32 gray + depth + sigma maps (12 B/px)",
                    "sequences_per_gpu": B, "frames_in_hbm_per_sequence": F, "sigma": a.sigma,
+                   "pyramid": ("frame k+1's pyramid built on a low-priority side stream while frame k tracks (--prefetch)" if a.prefetch else
+                               "every frame's pyramid built on the tracking stream ahead of its tracking (default; --prefetch overlaps it: "
+                               "+1 % frames/s, k_track_gn per-launch time +7 %)"),
                    "fixed_iterations": a.fixed_iters, "iterations_per_level_seq0": log0["n_iter"],
                    "note": "sigma = 0.1 is the reference's sensor-depth constant (transform.cpp:75): the Gauss-Newton step is 10x over-relaxed "
                            "(optimize.cpp:83-89), most sequences run to max_iterations = 15 on every level without converging",

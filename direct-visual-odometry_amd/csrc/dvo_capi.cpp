@@ -530,13 +530,12 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
     launch_set_pose(trk.state.as<SeqState>(), xin.as<float>(), 1, c.s);
     GnArgs ga;
     // per-pixel constants of the reference level (what build_pyramid does for whole frames)
-    DevBuf izb, wgb;
-    DVO_TRY(izb.alloc(n * 4));
+    DevBuf wgb;
     DVO_TRY(wgb.alloc(n * 4));
     {
         PrepArgs pa;
         memset(&pa, 0, sizeof pa);
-        pa.depth = rd.as<float>(); pa.sigma = rs.as<float>(); pa.iz = izb.as<float>(); pa.wgt = wgb.as<float>();
+        pa.depth = rd.as<float>(); pa.sigma = rs.as<float>(); pa.wgt = wgb.as<float>();
         pa.level_end[0] = n;
         pa.step[0] = trk.level_params(level).step;
         pa.sigma_min = cf.sigma_min; pa.sigma_max = cf.sigma_max;
@@ -544,7 +543,7 @@ int dvo_op_gn_step(int dev, const dvo_config* cfg, const float* obj_gray, const 
         launch_prep_ref(pa, c.s);
     }
     ga.obj_gray = og.as<float>(); ga.ref_gray = rg.as<float>(); ga.ref_depth = rd.as<float>();
-    ga.ref_iz = izb.as<float>(); ga.ref_wgt = wgb.as<float>();
+    ga.ref_wgt = wgb.as<float>();
     ga.state = trk.state.as<SeqState>();
     ga.partials = trk.partials.as<float>();
     ga.mask = mask ? mk.as<uint8_t>() : nullptr;

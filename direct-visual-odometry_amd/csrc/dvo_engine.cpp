@@ -147,11 +147,11 @@ int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
 {
     g = geo;
     n_seq = n;
-    DVO_TRY(arena.alloc(5 * g.px_total * (size_t)n * sizeof(float)));
+    DVO_TRY(arena.alloc(4 * g.px_total * (size_t)n * sizeof(float)));
     float* p = arena.as<float>();
-    for (int m = 0; m < 5; m++)
+    for (int m = 0; m < 4; m++)
         for (int l = 0; l < g.levels; l++) {
-            (m == 0 ? gray : m == 1 ? depth : m == 2 ? sigma : m == 3 ? iz : wgt)[l] = p;
+            (m == 0 ? gray : m == 1 ? depth : m == 2 ? sigma : wgt)[l] = p;
             p += (size_t)g.w[l] * g.h[l] * n;
         }
     for (int l = 0; l < g.levels; l++) step[l] = level_step(cfg, l);
@@ -160,12 +160,12 @@ int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
     return DVO_OK;
 }
 
-// iz / wgt of every level from the current depth / sigma pyramids (k_prep_ref)
+// wgt of every level from the current sigma pyramid (k_prep_ref)
 static void prep_reference(FrameSet& fs, hipStream_t s)
 {
     PrepArgs a;
     memset(&a, 0, sizeof a);
-    a.depth = fs.depth[0]; a.sigma = fs.sigma[0]; a.iz = fs.iz[0]; a.wgt = fs.wgt[0];  // levels are contiguous
+    a.depth = fs.depth[0]; a.sigma = fs.sigma[0]; a.wgt = fs.wgt[0];  // levels are contiguous
     size_t end = 0;
     for (int l = 0; l < fs.g.levels; l++) {
         end += (size_t)fs.g.w[l] * fs.g.h[l] * fs.n_seq;
@@ -180,7 +180,7 @@ static void prep_reference(FrameSet& fs, hipStream_t s)
 static void fuse_prep(PyramidArgs& a, const FrameSet& fs)
 {
     for (int l = 0; l < fs.g.levels; l++) {
-        a.iz[l] = fs.iz[l]; a.wgt[l] = fs.wgt[l];
+        a.wgt[l] = fs.wgt[l];
         a.step[l] = fs.step[l];
     }
     a.sigma_min = fs.sigma_min; a.sigma_max = fs.sigma_max;
@@ -396,7 +396,6 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     a.obj_gray = obj.gray[level];
     a.ref_gray = ref.gray[level];
     a.ref_depth = ref.depth[level];
-    a.ref_iz = ref.iz[level];
     a.ref_wgt = ref.wgt[level];
     a.state = state.as<SeqState>();
     a.partials = partials.as<float>();
@@ -481,7 +480,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 hipStream_t sk = k == 0 ? s : sub_streams[k - 1];
                 GnArgs ga = ga0;  // view of sequences [q0, q1)
                 ga.obj_gray += q0 * level_px; ga.ref_gray += q0 * level_px; ga.ref_depth += q0 * level_px;
-                ga.ref_iz += q0 * level_px; ga.ref_wgt += q0 * level_px;
+                ga.ref_wgt += q0 * level_px;
                 ga.state += q0;
                 ga.partials += (size_t)q0 * nblk[level] * 32;
                 if (single_launch[level]) {   // GN accumulation + solve of this iteration in one launch (k_track_gn_fused)

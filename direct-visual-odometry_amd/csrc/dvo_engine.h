@@ -60,10 +60,8 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
     float* gray[DVO_MAX_LEVELS] = {nullptr};
     float* depth[DVO_MAX_LEVELS] = {nullptr};
     float* sigma[DVO_MAX_LEVELS] = {nullptr};
-    // Per-pixel constants of a REFERENCE frame, derived once per frame instead of once per GN iteration:
-    // iz = 1.0f / depth and wgt = step(level) / clamp(sigma) (optimize.cpp:70-74,83-84).  Same float operations,
-    // hoisted out of the iteration loop.
-    float* iz[DVO_MAX_LEVELS] = {nullptr};
+    // Per-pixel constant of a REFERENCE frame, derived once per frame instead of once per GN iteration:
+    // wgt = step(level) / clamp(sigma) (optimize.cpp:83-84).  Same float operations, hoisted out of the iteration loop.
     float* wgt[DVO_MAX_LEVELS] = {nullptr};
     float step[DVO_MAX_LEVELS] = {0};
     float sigma_min = 0.01f, sigma_max = 0.5f;

@@ -24,8 +24,7 @@ struct PyramidArgs {
     int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS];
     float inv_tw;                      // 1 / top-level width
     int n_seq = 0;                     // set by launch_pyramid
-    // optional (iz[0] != nullptr, depth and sigma present): also write the k_prep_ref maps of every level
-    float* iz[DVO_MAX_LEVELS];
+    // optional (wgt[0] != nullptr, depth and sigma present): also write the k_prep_ref map of every level
     float* wgt[DVO_MAX_LEVELS];
     float step[DVO_MAX_LEVELS];
     float sigma_min, sigma_max;
@@ -56,8 +55,7 @@ struct GnArgs {
     const float* obj_gray;   // level buffers [n_seq][h][w]
     const float* ref_gray;
     const float* ref_depth;
-    const float* ref_iz;     // 1.0f / ref_depth            (k_prep_ref)
-    const float* ref_wgt;    // step / clamp(ref_sigma)     (k_prep_ref)
+    const float* ref_wgt;    // step / clamp(ref_sigma)     (k_prep_ref); 1 / ref_depth is recomputed per pixel (recip_rn: the IEEE quotient)
     const SeqState* state;
     float* partials;         // [n_seq][nblk][32]
     uint8_t* mask;           // optional [n_seq][h][w], pre-zeroed
@@ -83,7 +81,6 @@ struct GnArgs {
 struct PrepArgs {  // per-pixel constants of a reference frame, all levels in one launch
     const float* depth;      // level buffers are contiguous: [level][n_seq][h][w]
     const float* sigma;
-    float* iz;
     float* wgt;
     size_t level_end[DVO_MAX_LEVELS];  // cumulative element count after each level
     float step[DVO_MAX_LEVELS];
@@ -250,7 +247,7 @@ void launch_regularize_batch(const float* depth, const float* sigma, int w, int 
 struct RegDecArgs {
     const float* depth; const float* sigma;   // top level [n_seq][h][w], read only
     float* depth_top_out;                     // [n_seq][h][w]
-    float* depth_lv[DVO_MAX_LEVELS]; float* sigma_lv[DVO_MAX_LEVELS]; float* iz[DVO_MAX_LEVELS]; float* wgt[DVO_MAX_LEVELS];  // per level (top: iz, wgt only)
+    float* depth_lv[DVO_MAX_LEVELS]; float* sigma_lv[DVO_MAX_LEVELS]; float* wgt[DVO_MAX_LEVELS];  // per level (top: wgt only)
     int w[DVO_MAX_LEVELS], h[DVO_MAX_LEVELS], levels, n_seq;
     float step[DVO_MAX_LEVELS], sigma_min, sigma_max;
     float inv_w = 0.0f;                       // 1 / top-level width (set by the launch wrapper)

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
         }
     }
     // the reference-frame constants of k_prep_ref, written while depth and sigma are in registers (needs both maps)
-    const bool prep = a.iz[0] != nullptr && have[1] && have[2];
+    const bool prep = a.wgt[0] != nullptr && have[1] && have[2];
     for (int t = 0; t < a.levels; t++) {
         const int msk = (1 << t) - 1;
         if ((x & msk) | (y & msk)) break;  // level t below the top keeps pixels whose coordinates are multiples of 2^t
@@ -185,10 +185,7 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
             val[m] = (t == 0 && a.culls == 0) ? raw[m] : pass_valid(raw[m]);
             if (have[m] && a.dst[m][l] != nullptr) __builtin_nontemporal_store(val[m], a.dst[m][l] + o);  // (a map may be consumed without being kept; next read: a whole tracking step later)
         }
-        if (prep) {
-            __builtin_nontemporal_store(1.0f / val[1], a.iz[l] + o);
-            __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]), a.wgt[l] + o);
-        }
+        if (prep) __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, val[2]), a.wgt[l] + o);
     }
 }
 
@@ -239,27 +236,23 @@ __global__ void __launch_bounds__(256) k_pyramid_raw4(PyramidArgs a)
             if (a.raw_invalidate_gray && d == 0) raw[k][0] = kInvalid;
         }
     }
-    const bool prep = a.iz[0] != nullptr && dep;
+    const bool prep = a.wgt[0] != nullptr && dep;
     // top level (t = 0): cullImage(src, CULLS >= 1) -> pass_valid; four values per map, one 16-byte store
     {
         const int l = a.levels - 1;
         const size_t o = (size_t)seq * tw * th + (size_t)y * tw + x0;
         typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 v[3], izv, wgv;
+        f4 v[3], wgv;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float g = pass_valid(raw[k][0]), d = pass_valid(raw[k][1]), sg = pass_valid(raw[k][2]);
             v[0][k] = g; v[1][k] = d; v[2][k] = sg;
-            izv[k] = 1.0f / d;
             wgv[k] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, sg);
         }
         __builtin_nontemporal_store(v[0], reinterpret_cast<f4*>(a.dst[0][l] + o));
         if (dep && a.dst[1][l]) __builtin_nontemporal_store(v[1], reinterpret_cast<f4*>(a.dst[1][l] + o));
         if (dep && a.dst[2][l]) __builtin_nontemporal_store(v[2], reinterpret_cast<f4*>(a.dst[2][l] + o));
-        if (prep) {
-            __builtin_nontemporal_store(izv, reinterpret_cast<f4*>(a.iz[l] + o));
-            __builtin_nontemporal_store(wgv, reinterpret_cast<f4*>(a.wgt[l] + o));
-        }
+        if (prep) __builtin_nontemporal_store(wgv, reinterpret_cast<f4*>(a.wgt[l] + o));
     }
     for (int t = 1; t < a.levels; t++) {   // lower levels: pixels whose coordinates are multiples of 2^t
         const int msk = (1 << t) - 1;
@@ -277,10 +270,7 @@ __global__ void __launch_bounds__(256) k_pyramid_raw4(PyramidArgs a)
             __builtin_nontemporal_store(g, a.dst[0][l] + o);
             if (dep && a.dst[1][l]) __builtin_nontemporal_store(d, a.dst[1][l] + o);
             if (dep && a.dst[2][l]) __builtin_nontemporal_store(sg, a.dst[2][l] + o);
-            if (prep) {
-                __builtin_nontemporal_store(1.0f / d, a.iz[l] + o);
-                __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, sg), a.wgt[l] + o);
-            }
+            if (prep) __builtin_nontemporal_store(gn_weight(a.step[l], a.sigma_min, a.sigma_max, sg), a.wgt[l] + o);
         }
     }
 }
@@ -334,6 +324,27 @@ __global__ void __launch_bounds__(256) k_warp_image(const float* __restrict__ gr
 // Each thread owns PPT pixels (stride 256 => coalesced), keeps 29 accumulators (21 upper-tri J^T J, 6 J^T wr,
 // sum r^2, count), then: DPP wave sum -> LDS across the 4 waves -> one 32-float partial per workgroup.
 // ------------------------------------------------------------------------------------------------
+// 1.0f / d for the lanes that pass the gates of optimize.cpp:33-48 (d >= min_depth > 0), the IEEE quotient bit for bit: the
+// v_rcp_f32 + two-FMA form of dvo_math.h wherever it is proven equal to the division (|d| in [2^-100, 2^100], all floats compared
+// on the device), the division itself for the wave when a gated lane lies outside.  Lanes that fail the gate get an unspecified
+// finite-or-not value: their Jacobian row is replaced by zeros (a select, not a product) before it is used.
+__device__ __forceinline__ float recip_gated(float d, bool gate)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = recip_fast(d);
+    const float ad = fabsf(d);
+    const bool odd = gate & !((ad >= DVO_RECIP_FAST_MIN) & (ad <= DVO_RECIP_FAST_MAX));   // (true for NaN; min_depth is configurable)
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {       // wave-uniform; never taken for a real depth map
+        asm volatile("; recip_gated: IEEE division fallback");
+        if (odd) r = 1.0f / d;
+    }
+    return r;
+#else
+    (void)gate;
+    return 1.0f / d;
+#endif
+}
+
 struct Acc29 {
     float a[29];
     __device__ __forceinline__ void zero()
@@ -411,9 +422,10 @@ __device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, 
     valid = ((int)is_invalid(I2) | (int)is_invalid(gx) | (int)is_invalid(gy)) == 0;  // bitwise on purpose: no short-circuit branches
 }
 
-// k_prep_ref: per-pixel constants of a reference frame (all levels, one launch): iz = 1/depth and
-// wgt = step(level) / clamp(sigma) -- the two per-pixel divisions of optimize.cpp:70-74,83-84 that do not depend on
-// the pose, evaluated once per frame instead of once per Gauss-Newton iteration.
+// k_prep_ref: the per-pixel constant of a reference frame (all levels, one launch): wgt = step(level) / clamp(sigma) -- the
+// division of optimize.cpp:83-84, which does not depend on the pose, evaluated once per frame instead of once per Gauss-Newton
+// iteration.  (1 / depth, optimize.cpp:70-74, was a second such map in round 1: 4 B per pixel and iteration through HBM and the L1
+// for five instructions; the kernels now recompute it -- recip_rn, the IEEE quotient bit for bit.)
 __global__ void __launch_bounds__(256) k_prep_ref(PrepArgs a)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -422,7 +434,6 @@ __global__ void __launch_bounds__(256) k_prep_ref(PrepArgs a)
 #pragma unroll
     for (int l = 1; l < DVO_MAX_LEVELS; l++)
         if (l < a.levels && i >= a.level_end[l - 1]) step = a.step[l];
-    a.iz[i] = 1.0f / a.depth[i];
     a.wgt[i] = gn_weight(step, a.sigma_min, a.sigma_max, a.sigma[i]);
 }
 
@@ -488,7 +499,6 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
-    const float* __restrict__ izp = a.ref_iz + img_off;
     const float* __restrict__ wgp = a.ref_wgt + img_off;
     const float* __restrict__ refp = a.ref_gray + img_off;
     const float wlim = (float)(w - 2), hlim = (float)(h - 2);
@@ -532,13 +542,12 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
     }
     // every coalesced row load of this thread's PPT pixels is issued up front (independent of the pose): one exposed
     // memory round trip per wave instead of one per group
-    float dA[PPT], I1A[PPT], izA[PPT], wgA[PPT];
+    float dA[PPT], I1A[PPT], wgA[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, 1/depth, weight
+    for (int k = 0; k < PPT; k++) {  // ref_depth, obj_gray, weight
         const unsigned ic = (unsigned)iA[k] * 4u;  // byte offset: SGPR base + 32-bit VGPR offset
         dA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dep) + ic);
         I1A[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(obj) + ic);
-        izA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(izp) + ic);
         wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);
     }
 #pragma unroll
@@ -549,7 +558,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
         Taps t[G];
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            d[k] = dA[g0 + k]; I1[k] = I1A[g0 + k]; iz[k] = izA[g0 + k]; wg[k] = wgA[g0 + k];
+            d[k] = dA[g0 + k]; I1[k] = I1A[g0 + k]; wg[k] = wgA[g0 + k];
         }
 #pragma unroll
         for (int k = 0; k < G; k++) {  // gates, warp, issue the gathers (always from a safe address)
@@ -558,6 +567,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             bool crop_ok = true;
             if (a.prm.crop) crop_ok = (xs[k] >= 20) & (xs[k] <= 140) & (ys[k] >= 20) & (ys[k] <= 100);  // wave-uniform branch
             gate[k] = inA[g0 + k] & crop_ok & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
+            iz[k] = recip_gated(d[k], gate[k]);   // 1.0f / depth (optimize.cpp:70-74) of the pixels that can contribute
             warp(pose, a.k, (float)xs[k], (float)ys[k], d[k], u[k], v[k]);
             inter[k] = gate[k] & (u[k] >= 1.0f) & (v[k] >= 1.0f) & (u[k] < wlim) & (v[k] < hlim);  // false for NaN
             x0[k] = inter[k] ? (int)u[k] : 1;
@@ -623,7 +633,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             const int i = slow_q[qw][e - qoff];  // < npix (only gated pixels are queued)
             int x, y;
             split_index(i, w, a.inv_w, x, y);
-            const float d = dep[i], I1 = obj[i], iz = izp[i], wg = wgp[i];
+            const float d = dep[i], I1 = obj[i], iz = recip_gated(dep[i], true), wg = wgp[i];
             float u, v;
             warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
             // inlined (single site): a call here would pin the 29 live accumulators to callee-saved registers and
@@ -686,7 +696,6 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
     const size_t img_off = (size_t)seq * w * h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
-    const float* __restrict__ izp = a.ref_iz + img_off;
     const float* __restrict__ wgp = a.ref_wgt + img_off;
     const float* __restrict__ refp = a.ref_gray + img_off;
 
@@ -700,7 +709,7 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         const int i = yc * w + xc;
         d[k] = dep[i];
         I1[k] = obj[i];
-        iz[k] = izp[i];
+        iz[k] = 0.0f;
         wg[k] = wgp[i];
     }
     const int M = a.margin, PW = 64 + 2 * M + 3;
@@ -721,6 +730,7 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         const int y = ty0 + wave + 4 * k;
         const int crop_ok = (a.prm.crop == 0) | ((x >= 20) & (x <= 140) & (y >= 20) & (y <= 100));
         const bool gate = (x < w) & (y < h) & (crop_ok != 0) & !(d[k] < a.prm.min_depth) & !is_invalid(I1[k]);
+        iz[k] = recip_gated(d[k], gate);
         float u, v;
         warp(pose, a.k, (float)x, (float)y, d[k], u, v);
         const bool inter = gate & (u >= 1.0f) & (v >= 1.0f) & (u < wlim) & (v < hlim);  // false for NaN
@@ -1304,7 +1314,7 @@ void launch_pyramid(const PyramidArgs& a0, int n_seq, hipStream_t s)
     bool aligned = true;   // the 16-byte top-level stores
     {
         const int T = a.levels - 1;
-        const void* tops[5] = {a.dst[0][T], a.dst[1][T], a.dst[2][T], a.iz[T], a.wgt[T]};
+        const void* tops[4] = {a.dst[0][T], a.dst[1][T], a.dst[2][T], a.wgt[T]};
         for (const void* p : tops) aligned = aligned && (reinterpret_cast<uintptr_t>(p) % 16) == 0;
         aligned = aligned && ((size_t)tw * th % 4) == 0;
     }

@@ -251,7 +251,6 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
     regularize_fuse4(depth, sigma, i, x, y, w, h, gd, gs);
     const float nd = gd < 6.0f ? gd : 6.0f;                       // implement.cpp:178
     a.depth_top_out[base + i] = nd;                               // top level: the map itself (cullImage(src, 0) aliases, convert.cpp:9-10)
-    __builtin_nontemporal_store(1.0f / nd, a.iz[T] + base + i);
     __builtin_nontemporal_store(gn_weight(a.step[T], a.sigma_min, a.sigma_max, s0), a.wgt[T] + base + i);
     const float vd = pass_valid(nd), vs = pass_valid(s0);
     for (int t = 1; t < a.levels; t++) {                          // lower levels keep pixels whose coordinates are multiples of 2^t
@@ -262,7 +261,6 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
         const size_t o = (size_t)seq * a.w[l] * a.h[l] + (size_t)ly * a.w[l] + lx;
         a.depth_lv[l][o] = vd;
         a.sigma_lv[l][o] = vs;
-        a.iz[l][o] = 1.0f / vd;
         a.wgt[l][o] = gn_weight(a.step[l], a.sigma_min, a.sigma_max, vs);
     }
 }

@@ -191,7 +191,7 @@ int MonoBatch::odometrize(const FrameInput& in)
         ra.depth_top_out = depth_alt;
         for (int l = 0; l < g.levels; l++) {
             ra.w[l] = g.w[l]; ra.h[l] = g.h[l];
-            ra.depth_lv[l] = ref.depth[l]; ra.sigma_lv[l] = ref.sigma[l]; ra.iz[l] = ref.iz[l]; ra.wgt[l] = ref.wgt[l];
+            ra.depth_lv[l] = ref.depth[l]; ra.sigma_lv[l] = ref.sigma[l]; ra.wgt[l] = ref.wgt[l];
             ra.step[l] = ref.step[l];
         }
         ra.levels = g.levels; ra.n_seq = n_seq; ra.sigma_min = ref.sigma_min; ra.sigma_max = ref.sigma_max;
