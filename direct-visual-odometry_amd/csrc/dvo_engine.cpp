@@ -186,12 +186,15 @@ static void fuse_prep(PyramidArgs& a, const FrameSet& fs)
     a.sigma_min = fs.sigma_min; a.sigma_max = fs.sigma_max;
 }
 
-void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma)
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma,
+                   bool rows_decimated)
 {
     PyramidArgs a;
     memset(&a, 0, sizeof a);
     a.src[0] = gray_dev; a.src[1] = depth_dev; a.src[2] = sigma_dev;
     a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
+    a.src_img_rows = rows_decimated ? fs.g.src_h >> fs.g.culls : fs.g.src_h;
+    a.src_row_shift = rows_decimated ? 0 : fs.g.culls;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
         a.dst[0][l] = fs.gray[l]; a.dst[1][l] = fs.depth[l];
@@ -204,15 +207,15 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
 
 void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_sigma)
 {
-    if (!in.raw()) { build_pyramid(fs, in.gray, in.depth, in.sigma, s, keep_sigma); return; }
+    if (!in.raw()) { build_pyramid(fs, in.gray, in.depth, in.sigma, s, keep_sigma, in.rows_decimated); return; }
     PyramidArgs a;
     memset(&a, 0, sizeof a);
     a.raw_rgb = in.rgb; a.raw_channels = in.channels; a.raw_depth = in.depth16;
     a.raw_gray_scale = (float)(1.0 / 255.0); a.raw_depth_scale = in.depth_scale;
     a.raw_sigma_valid = 0.1f; a.raw_sigma_invalid = 1.0f; a.raw_invalidate_gray = 1;   // transform.cpp:60-76
     a.src_w = fs.g.src_w; a.src_h = fs.g.src_h; a.culls = fs.g.culls; a.levels = fs.g.levels;
-    a.raw_img_rows = in.rows_decimated ? fs.g.src_h >> fs.g.culls : fs.g.src_h;
-    a.raw_row_shift = in.rows_decimated ? 0 : fs.g.culls;
+    a.src_img_rows = in.rows_decimated ? fs.g.src_h >> fs.g.culls : fs.g.src_h;
+    a.src_row_shift = in.rows_decimated ? 0 : fs.g.culls;
     const bool dep = in.depth16 != nullptr;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
@@ -225,7 +228,7 @@ void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_
     launch_pyramid(a, fs.n_seq, s);
 }
 
-int upload_raw_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
+int upload_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
                     size_t* stored)
 {
     if (!decimate || culls <= 0) {
@@ -249,6 +252,7 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
     const int T = fs.g.top();
     a.src[1] = depth_top; a.src[2] = sigma_top;
     a.src_w = fs.g.w[T]; a.src_h = fs.g.h[T]; a.culls = 0; a.levels = fs.g.levels;
+    a.src_img_rows = a.src_h; a.src_row_shift = 0;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
         a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
@@ -738,10 +742,11 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
         const size_t px = (size_t)w * h;
         if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
         fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps cross PCIe
-        DVO_TRY(upload_raw_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
+        DVO_TRY(upload_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
         fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
     } else {
-        DVO_HIP(hipMemcpyAsync(in_gray.p, gray, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, stream));
+        fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);
+        DVO_TRY(upload_rows(in_gray.p, gray, (size_t)w * sizeof(float), h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
         fin.gray = in_gray.as<float>();
     }
     if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg)); }
@@ -808,11 +813,14 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
     if (!gray || !depth || !sigma || !T_rel) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
     if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
-    const size_t n = (size_t)w * h * sizeof(float);
-    DVO_HIP(hipMemcpyAsync(in_gray.p, gray, n, hipMemcpyHostToDevice, stream));
-    DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
-    DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
-    return odometrize_depth_staged(T_rel);
+    FrameInput in;   // float maps: only the rows the pyramid keeps cross PCIe (upload_rows)
+    in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);
+    const size_t rb = (size_t)w * sizeof(float);
+    DVO_TRY(upload_rows(in_gray.p, gray, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_TRY(upload_rows(in_depth.p, depth, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_TRY(upload_rows(in_sigma.p, sigma, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    in.gray = in_gray.as<float>(); in.depth = in_depth.as<float>(); in.sigma = in_sigma.as<float>();
+    return odometrize_depth_staged(T_rel, &in);
 }
 
 int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
@@ -823,8 +831,8 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
     FrameInput in;
     in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);   // only the rows the pyramid keeps cross PCIe
-    DVO_TRY(upload_raw_rows(raw_rgb.p, rgb, (size_t)w * channels, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
-    DVO_TRY(upload_raw_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_TRY(upload_rows(raw_rgb.p, rgb, (size_t)w * channels, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_TRY(upload_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
     in.rgb = raw_rgb.as<uint8_t>(); in.channels = channels; in.depth16 = raw_depth.as<uint16_t>(); in.depth_scale = depth_scale;
     return odometrize_depth_staged(T_rel, &in);
 }
@@ -835,7 +843,7 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* r
     if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
     Keyframe& frame = *depth_cur;
     frame.id = ++latest_id;
-    if (raw) build_pyramid(frame.fs, *raw, stream);
+    if (raw) build_pyramid(frame.fs, *raw, stream);   // (raw sensor frame or float maps staged by the caller)
     else build_pyramid(frame.fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
     const float z[6] = {0, 0, 0, 0, 0, 0};
     if (!depth_ref) {  // system.hpp:83-86
@@ -923,12 +931,14 @@ int Batch::push_host_frame(const void* p0, size_t n0, const void* p1, size_t n1,
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
     if (in.raw()) {  // only the rows the pyramid keeps cross PCIe (the staging buffers are sized for whole frames)
         in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
-        DVO_TRY(upload_raw_rows(st.a.p, p0, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
-        DVO_TRY(upload_raw_rows(st.b.p, p1, (size_t)g.src_w * 2, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        DVO_TRY(upload_rows(st.a.p, p0, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        DVO_TRY(upload_rows(st.b.p, p1, (size_t)g.src_w * 2, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
     } else {
-        DVO_HIP(hipMemcpyAsync(st.a.p, p0, n0, hipMemcpyHostToDevice, cstream));
-        if (p1) DVO_HIP(hipMemcpyAsync(st.b.p, p1, n1, hipMemcpyHostToDevice, cstream));
-        if (p2) DVO_HIP(hipMemcpyAsync(st.c.p, p2, n2, hipMemcpyHostToDevice, cstream));
+        in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
+        const size_t rb = (size_t)g.src_w * sizeof(float);
+        DVO_TRY(upload_rows(st.a.p, p0, rb, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        if (p1) DVO_TRY(upload_rows(st.b.p, p1, rb, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        if (p2) DVO_TRY(upload_rows(st.c.p, p2, rb, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
     }
     DVO_HIP(hipEventRecord(st.copied, cstream));
     // Pageable memory: the runtime may pin it in place and return while the DMA is still reading it, and the caller is free to

@@ -70,24 +70,25 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
 
 // Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
 // keep_sigma = false: the sigma pyramid is only folded into `wgt`, not stored (frame-to-frame tracking never reads it again)
-void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma = true);
+void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, const float* sigma_dev, hipStream_t s, bool keep_sigma = true,
+                   bool rows_decimated = false);
 // One frame of every sequence as handed over by the caller: float maps (gray [+ depth + sigma]) or raw sensor frames
 // (u8 gray / RGB / RGBA [+ u16 depth], converted while the pyramid is built: loader.cpp:55-60,137-147, transform.cpp:60-76).
 struct FrameInput {
     const float* gray = nullptr; const float* depth = nullptr; const float* sigma = nullptr;
     const uint8_t* rgb = nullptr; int channels = 0; const uint16_t* depth16 = nullptr; float depth_scale = 1.0f / 5000.0f;
-    bool rows_decimated = false;  // raw buffers hold only the rows the pyramid keeps (every 2^culls-th), see Batch::push_host_frame
+    bool rows_decimated = false;  // the buffers hold only the rows the pyramid keeps (every 2^culls-th), see upload_rows
     bool raw() const { return rgb != nullptr; }
     const void* key0() const { return raw() ? (const void*)rgb : (const void*)gray; }
     const void* key1() const { return raw() ? (const void*)depth16 : (const void*)depth; }
     bool has_depth() const { return raw() ? depth16 != nullptr : (depth != nullptr && sigma != nullptr); }
 };
 void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_sigma = true);
-// Host -> device copy of raw frames of n_img images (rows of row_bytes bytes).  With culls > 0 and decimate set only every
+// Host -> device copy of n_img images (raw or float; rows of row_bytes bytes).  With culls > 0 and decimate set only every
 // 2^culls-th row of each image is transferred (one strided DMA): the pyramid never reads the others (Convert::cullImage keeps
 // pixels whose coordinates are multiples of 2^culls), so 1 - 2^-culls of the PCIe traffic carries nothing.  Returns the bytes
 // the device buffer holds through *stored.
-int upload_raw_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
+int upload_rows(void* dst, const void* src, size_t row_bytes, int img_rows, size_t n_img, int culls, bool decimate, hipStream_t s,
                     size_t* stored);
 inline bool can_decimate_rows(const Geometry& g) { return g.culls > 0 && (g.src_h % (1 << g.culls)) == 0; }
 // Frame::updateDepthSigma / updateDepth (frame.cpp:39-61): re-decimate from a top-level map (may alias the top level)

@@ -34,9 +34,9 @@ struct PyramidArgs {
     const uint8_t* raw_rgb;      // [n_seq][src_h][src_w][raw_channels], channels 1 (gray), 3 (R,G,B) or 4 (R,G,B,A)
     const uint16_t* raw_depth;   // [n_seq][src_h][src_w]
     int raw_channels, raw_invalidate_gray;
-    // raw buffers hold raw_img_rows rows per image and top-level row y comes from stored row y << raw_row_shift: (src_h, culls) for
-    // a whole frame, (src_h >> culls, 0) when the host uploaded only the rows the pyramid keeps (Batch::push_host_frame)
-    int raw_img_rows, raw_row_shift;
+    // the input buffers (raw or float) hold src_img_rows rows per image and top-level row y comes from stored row y << src_row_shift:
+    // (src_h, culls) for a whole frame, (src_h >> culls, 0) when the host uploaded only the rows the pyramid keeps (upload_rows)
+    int src_img_rows, src_row_shift;
     float raw_gray_scale, raw_depth_scale, raw_sigma_valid, raw_sigma_invalid;
 };
 

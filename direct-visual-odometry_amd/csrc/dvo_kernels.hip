@@ -143,11 +143,10 @@ __global__ void __launch_bounds__(256) k_pyramid(PyramidArgs a)
     if (i >= tw * th || seq >= a.n_seq) return;
     int x, y;
     split_index(i, tw, a.inv_tw, x, y);
-    size_t src_off = (size_t)seq * a.src_w * a.src_h + (size_t)(y << a.culls) * a.src_w + (x << a.culls);
+    const size_t src_off = (size_t)seq * a.src_w * a.src_img_rows + (size_t)(y << a.src_row_shift) * a.src_w + (x << a.culls);
     float raw[3] = {0.0f, 0.0f, 0.0f};
     bool have[3];
     if (a.raw_rgb != nullptr) {  // raw sensor frame: convert exactly as k_ingest does (same float operations), only the kept pixels
-        src_off = (size_t)seq * a.src_w * a.raw_img_rows + (size_t)(y << a.raw_row_shift) * a.src_w + (x << a.culls);
         unsigned g8;
         if (a.raw_channels == 1) {
             g8 = __builtin_nontemporal_load(a.raw_rgb + src_off);
@@ -205,7 +204,7 @@ __global__ void __launch_bounds__(256) k_pyramid_raw4(PyramidArgs a)
     int y, xg;
     split_index(gi, gw, a.inv_tw * 4.0f, xg, y);   // (4 / tw = 1 / gw up to an ulp: split_index corrects +-1)
     const int x0 = xg << 2;
-    const size_t src_off = (size_t)seq * a.src_w * a.raw_img_rows + (size_t)(y << a.raw_row_shift) * a.src_w + ((size_t)x0 << CULLS);
+    const size_t src_off = (size_t)seq * a.src_w * a.src_img_rows + (size_t)(y << a.src_row_shift) * a.src_w + ((size_t)x0 << CULLS);
     constexpr int GW = 1 << CULLS;       // 32-bit words of gray bytes this thread reads (2 or 4)
     unsigned gwords[GW], dwords[2 * GW];
     const bool dep = a.raw_depth != nullptr;

@@ -94,9 +94,10 @@ int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
     if (in.raw()) {  // only the rows the pyramid keeps cross PCIe (Batch::push_host_frame)
         in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
-        DVO_TRY(upload_raw_rows(st.buf.p, frames, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
+        DVO_TRY(upload_rows(st.buf.p, frames, (size_t)g.src_w * in.channels, g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
     } else {
-        DVO_HIP(hipMemcpyAsync(st.buf.p, frames, bytes, hipMemcpyHostToDevice, cstream));
+        in.rows_decimated = decimate_host_rows && can_decimate_rows(g);
+        DVO_TRY(upload_rows(st.buf.p, frames, (size_t)g.src_w * sizeof(float), g.src_h, (size_t)n_seq, g.culls, in.rows_decimated, cstream, nullptr));
     }
     DVO_HIP(hipEventRecord(st.copied, cstream));
     if (!host_buffer_is_pinned(frames)) DVO_HIP(hipStreamSynchronize(cstream));   // pageable source: see Batch::push_host_frame
