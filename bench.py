@@ -58,7 +58,7 @@ def parse():
                     "time -- the roofline figure -- reads 7 % longer; default: every pyramid in order on the tracking stream")
     ap.add_argument("--no-prefetch", action="store_true", help="(the default since round 2; kept for old command lines)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-stream side measurements")
-    ap.add_argument("--pcie-steps", type=int, default=8, help="steps of the PCIe-inclusive side measurement (0 = skip)")
+    ap.add_argument("--pcie-steps", type=int, default=16, help="steps of the PCIe-inclusive side measurement (0 = skip)")
     return ap.parse_args()
 
 
