@@ -157,6 +157,7 @@ int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
     for (int l = 0; l < g.levels; l++) step[l] = level_step(cfg, l);
     sigma_min = cfg.sigma_min;
     sigma_max = cfg.sigma_max;
+    allow_const_weight = cfg.min_depth > 0.0f;
     return DVO_OK;
 }
 
@@ -201,7 +202,8 @@ void build_pyramid(FrameSet& fs, const float* gray_dev, const float* depth_dev, 
         a.dst[2][l] = (keep_sigma || !(depth_dev && sigma_dev)) ? fs.sigma[l] : nullptr;
     }
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
-    if (depth_dev && sigma_dev) fuse_prep(a, fs);  // iz / wgt written by the same launch (no k_prep_ref pass)
+    fs.sigma_by_validity = false;
+    if (depth_dev && sigma_dev) fuse_prep(a, fs);  // wgt written by the same launch (no k_prep_ref pass)
     launch_pyramid(a, fs.n_seq, s);
 }
 
@@ -224,7 +226,12 @@ void build_pyramid(FrameSet& fs, const FrameInput& in, hipStream_t s, bool keep_
         a.dst[2][l] = (dep && keep_sigma) ? fs.sigma[l] : nullptr;
     }
     a.inv_tw = 1.0f / (float)fs.g.w[fs.g.top()];
-    if (dep) fuse_prep(a, fs);
+    fs.sigma_by_validity = dep && !keep_sigma && fs.allow_const_weight;
+    if (fs.sigma_by_validity) {  // no wgt maps: the weight of every pixel that can contribute is a constant of the level
+        for (int l = 0; l < fs.g.levels; l++) fs.wgt_valid[l] = gn_weight(fs.step[l], fs.sigma_min, fs.sigma_max, a.raw_sigma_valid);
+    } else if (dep) {
+        fuse_prep(a, fs);
+    }
     launch_pyramid(a, fs.n_seq, s);
 }
 
@@ -253,6 +260,7 @@ void redecimate(FrameSet& fs, const float* depth_top, const float* sigma_top, hi
     a.src[1] = depth_top; a.src[2] = sigma_top;
     a.src_w = fs.g.w[T]; a.src_h = fs.g.h[T]; a.culls = 0; a.levels = fs.g.levels;
     a.src_img_rows = a.src_h; a.src_row_shift = 0;
+    fs.sigma_by_validity = false;
     for (int l = 0; l < fs.g.levels; l++) {
         a.w[l] = fs.g.w[l]; a.h[l] = fs.g.h[l];
         a.dst[1][l] = fs.depth[l]; a.dst[2][l] = fs.sigma[l];
@@ -400,7 +408,8 @@ GnArgs Tracker::gn_args(const FrameSet& obj, const FrameSet& ref, int level, uin
     a.obj_gray = obj.gray[level];
     a.ref_gray = ref.gray[level];
     a.ref_depth = ref.depth[level];
-    a.ref_wgt = ref.wgt[level];
+    a.ref_wgt = ref.sigma_by_validity ? nullptr : ref.wgt[level];
+    a.wgt_const = ref.sigma_by_validity ? ref.wgt_valid[level] : 0.0f;
     a.state = state.as<SeqState>();
     a.partials = partials.as<float>();
     a.mask = mask;
@@ -484,7 +493,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
                 hipStream_t sk = k == 0 ? s : sub_streams[k - 1];
                 GnArgs ga = ga0;  // view of sequences [q0, q1)
                 ga.obj_gray += q0 * level_px; ga.ref_gray += q0 * level_px; ga.ref_depth += q0 * level_px;
-                ga.ref_wgt += q0 * level_px;
+                if (ga.ref_wgt) ga.ref_wgt += q0 * level_px;
                 ga.state += q0;
                 ga.partials += (size_t)q0 * nblk[level] * 32;
                 if (single_launch[level]) {   // GN accumulation + solve of this iteration in one launch (k_track_gn_fused)

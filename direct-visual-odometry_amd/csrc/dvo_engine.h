@@ -63,6 +63,11 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
     // Per-pixel constant of a REFERENCE frame, derived once per frame instead of once per GN iteration:
     // wgt = step(level) / clamp(sigma) (optimize.cpp:83-84).  Same float operations, hoisted out of the iteration loop.
     float* wgt[DVO_MAX_LEVELS] = {nullptr};
+    // Frames that came through the raw sensor conversion without a stored sigma pyramid carry sigma = 0.1 where depth > 0 and 1.0
+    // elsewhere (transform.cpp:75): a pixel can only contribute with depth >= min_depth > 0, so its weight is the one constant
+    // wgt_valid[level] and the wgt maps are neither written nor read (allow_const_weight: min_depth > 0).
+    bool allow_const_weight = false, sigma_by_validity = false;
+    float wgt_valid[DVO_MAX_LEVELS] = {0};
     float step[DVO_MAX_LEVELS] = {0};
     float sigma_min = 0.01f, sigma_max = 0.5f;
     int alloc(const Geometry& geo, int n, const dvo_config& cfg);

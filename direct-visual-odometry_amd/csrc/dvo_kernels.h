@@ -56,6 +56,7 @@ struct GnArgs {
     const float* ref_gray;
     const float* ref_depth;
     const float* ref_wgt;    // step / clamp(ref_sigma)     (k_prep_ref); 1 / ref_depth is recomputed per pixel (recip_rn: the IEEE quotient)
+    float wgt_const = 0.0f;  // ref_wgt == nullptr: the weight of every pixel that can contribute (FrameSet::sigma_by_validity)
     const SeqState* state;
     float* partials;         // [n_seq][nblk][32]
     uint8_t* mask;           // optional [n_seq][h][w], pre-zeroed

@@ -498,7 +498,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
     const size_t img_off = (size_t)seq * a.w * a.h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
-    const float* __restrict__ wgp = a.ref_wgt + img_off;
+    const float* __restrict__ wgp = a.ref_wgt ? a.ref_wgt + img_off : nullptr;   // nullptr: one weight for every contributing pixel
     const float* __restrict__ refp = a.ref_gray + img_off;
     const float wlim = (float)(w - 2), hlim = (float)(h - 2);
 
@@ -547,7 +547,8 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
         const unsigned ic = (unsigned)iA[k] * 4u;  // byte offset: SGPR base + 32-bit VGPR offset
         dA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dep) + ic);
         I1A[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(obj) + ic);
-        wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);
+        wgA[k] = a.wgt_const;
+        if (wgp) wgA[k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wgp) + ic);   // (wave-uniform)
     }
 #pragma unroll
     for (int g0 = 0; g0 < PPT; g0 += G) {
@@ -632,7 +633,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             const int i = slow_q[qw][e - qoff];  // < npix (only gated pixels are queued)
             int x, y;
             split_index(i, w, a.inv_w, x, y);
-            const float d = dep[i], I1 = obj[i], iz = recip_gated(dep[i], true), wg = wgp[i];
+            const float d = dep[i], I1 = obj[i], iz = recip_gated(dep[i], true), wg = wgp ? wgp[i] : a.wgt_const;
             float u, v;
             warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
             // inlined (single site): a call here would pin the 29 live accumulators to callee-saved registers and
@@ -695,7 +696,7 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
     const size_t img_off = (size_t)seq * w * h;
     const float* __restrict__ obj = a.obj_gray + img_off;
     const float* __restrict__ dep = a.ref_depth + img_off;
-    const float* __restrict__ wgp = a.ref_wgt + img_off;
+    const float* __restrict__ wgp = a.ref_wgt ? a.ref_wgt + img_off : nullptr;
     const float* __restrict__ refp = a.ref_gray + img_off;
 
     // ---- one burst of global loads: own pixels (registers) + reference patch (LDS) ----
@@ -709,7 +710,7 @@ __global__ void __launch_bounds__(256) k_track_gn_tile(GnArgs a)
         d[k] = dep[i];
         I1[k] = obj[i];
         iz[k] = 0.0f;
-        wg[k] = wgp[i];
+        wg[k] = wgp ? wgp[i] : a.wgt_const;
     }
     const int M = a.margin, PW = 64 + 2 * M + 3;
     const int px0 = max(tx0 - M - 1, 0), px1 = min(tx0 + 64 + M + 2, w);  // staged columns [px0, px1)
