@@ -157,7 +157,7 @@ int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
     for (int l = 0; l < g.levels; l++) step[l] = level_step(cfg, l);
     sigma_min = cfg.sigma_min;
     sigma_max = cfg.sigma_max;
-    allow_const_weight = cfg.min_depth > 0.0f;
+    allow_const_weight = cfg.min_depth > 0.0f && getenv("DVO_WEIGHT_MAPS") == nullptr;   // (the variable forces the maps: A/B runs, tests)
     return DVO_OK;
 }
 

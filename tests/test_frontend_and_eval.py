@@ -235,10 +235,12 @@ def test_batch_raw_push_equals_float_push(channels):
     def run(mode):
         if mode == "host_full":   # whole frames over PCIe (the default transfers only the rows the pyramid keeps: one strided copy)
             os.environ["DVO_UPLOAD_FULL_FRAMES"] = "1"
+            os.environ["DVO_WEIGHT_MAPS"] = "1"   # ... and the per-pixel weight maps instead of the constant weight of raw sensor frames
         try:
             bt = dvo.Batch(B, K640, 640, 480, 4, 1, cfg=dvo.default_config(gn_pixels_per_thread=4))
         finally:
             os.environ.pop("DVO_UPLOAD_FULL_FRAMES", None)
+            os.environ.pop("DVO_WEIGHT_MAPS", None)
         out = []
         if mode == "device":
             dev = torch.device("cuda", 0)
