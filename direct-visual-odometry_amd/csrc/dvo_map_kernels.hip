@@ -269,6 +269,13 @@ __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
 // One reference pixel of Mapper::update + Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214).  The per-keyframe
 // relative poses come from k_age_table (never a per-pixel exp/log).  Split in a head (up to the epipolar segment, which fixes the
 // number of search steps) and a tail (the search and what follows), so that k_depth_update can reorder pixels between the two.
+// GlobalImg (dvo_math.h) with the address space stated: a keyframe image reached through a pointer table is otherwise a flat pointer
+struct GlobalImgG {
+    const __attribute__((address_space(1))) float* p;
+    int w, h;
+    __device__ __forceinline__ float at(int x, int y) const { return p[y * w + x]; }
+};
+
 struct UpdHead {   // what the head of the per-pixel computation hands to the search (kept in LDS between the two phases of k_depth_update)
     float sx, sy, ex, ey, length, depth, sigma, dmin, dmax;
     int qx, qy, bi;
@@ -324,7 +331,7 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
     const int obj_id = m ? m->frame_id : a.obj_id;
     const AgeEntry& born = a.ages[(size_t)seq * a.R + hd.bi];
     const float* born_gray = a.ring_gray ? a.ring_gray + ((size_t)seq * a.R + born.slot) * npix : a.gray_table[born.slot];
-    const GlobalImg bg{born_gray, w, h};
+    const GlobalImgG bg{(const __attribute__((address_space(1))) float*)born_gray, w, h};
     const float sx = hd.sx, sy = hd.sy, ex = hd.ex, ey = hd.ey, length = hd.length, depth = hd.depth, sigma = hd.sigma, dmin = hd.dmin, dmax = hd.dmax;
     const int qx = hd.qx, qy = hd.qy;
     const float sex = sx - ex, sey = sy - ey;
@@ -371,7 +378,9 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
                 const float kf = (float)(jj - 1);
                 const float px = ptx + dirx * kf, py = pty + diry * kf;
                 const int x0 = (int)px, y0 = (int)py;
-                const float* q = born_gray + (y0 * w + x0);
+                // (global address space stated: born_gray may come from a pointer table, which makes it a flat pointer -- and flat loads
+                //  also count against lgkmcnt and take the aperture check)
+                const __attribute__((address_space(1))) float* q = (const __attribute__((address_space(1))) float*)born_gray + (y0 * w + x0);
                 sgv[jj] = blend4(q[0], q[1], q[w], q[w + 1], px - (float)x0, py - (float)y0);
             }
         } else {
