@@ -392,3 +392,51 @@ def test_trajectory_ate_gpu_vs_oracle_on_synthetic_ground_truth():
     assert abs(ate_g - ate_o) < 1e-3                      # BASELINE.json: within 1e-3 m of the reference path
     assert np.abs(xg - xo).max() < 1e-3                   # and the two trajectories coincide frame by frame
     assert ate_g < 0.05                                    # sanity: it does track (path length ~ 0.1 m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels,culls", [(646, 486, 4, 1), (640, 484, 3, 2), (328, 248, 3, 1), (330, 250, 2, 1), (96, 72, 2, 2)])
+def test_host_uploads_of_odd_sizes_equal_device_frames(w, h, levels, culls):
+    """The row-decimated host upload (one strided copy per buffer, rows r = 0 mod 2^culls of the caller's [n_seq][h][w] buffer)
+    against the same frames already resident on the device, for sizes where the vector pyramid kernel does not apply (widths that are
+    no multiple of 4 << culls), where the decimation does not apply (heights that are no multiple of 2^culls) and for both input
+    kinds (raw u8 + u16, float maps): poses and per-iteration logs bit-identical."""
+    import torch
+    from dvo_amd import synth
+    K = np.array(synth.K_640, np.float32).copy()
+    K[0] *= w / 640.0; K[1] *= h / 480.0
+    g, d, s, _ = synth.sequence(3, width=w, height_px=h, K=K, seed=17, sigma_value=0.1)
+    g, d = g.numpy(), d.numpy()
+    B = 2
+    g8 = [np.stack([np.clip(np.rint(g[(k + b) % 3] * 255), 0, 255).astype(np.uint8) for b in range(B)]) for k in range(3)]
+    d16 = [np.stack([np.clip(np.rint(d[(k + b) % 3] * 5000), 0, 65535).astype(np.uint16) for b in range(B)]) for k in range(3)]
+    fl = [[dvo.ingest(g8[k][b], d16[k][b]) for b in range(B)] for k in range(3)]
+    dev = torch.device("cuda", 0)
+    def run(mode):
+        bt = dvo.Batch(B, K, w, h, levels, culls, cfg=dvo.default_config(gn_pixels_per_thread=4))
+        out = []
+        for k in range(3):
+            if mode == "raw_host":
+                bt.push_raw_host(g8[k], d16[k])
+            elif mode == "raw_device":
+                tg = torch.from_numpy(g8[k]).to(dev); td = torch.from_numpy(d16[k].view(np.int16)).to(dev); torch.cuda.synchronize()
+                bt.push_raw_device(tg.data_ptr(), 1, td.data_ptr())
+            elif mode == "float_host":
+                bt.push_host(np.stack([f[0] for f in fl[k]]), np.stack([f[1] for f in fl[k]]), np.stack([f[2] for f in fl[k]]))
+            else:
+                t = [torch.from_numpy(np.stack([f[m] for f in fl[k]])).to(dev) for m in range(3)]; torch.cuda.synchronize()
+                bt.push_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+            if k > 0:
+                bt.synchronize()
+                out.append((bt.last_poses()[0].copy(), [bt.last_track_log(b)["residual"] for b in range(B)]))
+        bt.close()
+        return out
+    ref = run("raw_device")
+    assert np.abs(ref[-1][0]).max() > 1e-6
+    for mode in ("raw_host", "float_host", "float_device"):
+        got = run(mode)
+        for (xa, la), (xb, lb) in zip(ref, got):
+            np.testing.assert_array_equal(xa, xb, err_msg=mode)
+            for b in range(B):
+                for l in range(levels):
+                    np.testing.assert_array_equal(la[b][l], lb[b][l], err_msg=mode)

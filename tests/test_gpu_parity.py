@@ -555,3 +555,88 @@ def test_levels_smaller_than_4x4_are_refused():
         dvo.optimize(g, g, g + 1.0, g, K, np.zeros(6, np.float32), 0)
     bt = dvo.Batch(2, K, 64, 32, levels=4, culls=0)        # coarsest level 8 x 4: the smallest that is accepted
     bt.close()
+
+
+def test_randomized_gn_step_sweep():
+    """Fixed-seed sweep of Track::optimize (optimize.cpp:10-99) over what the targeted tests fix by hand: image sizes from the
+    4 x 4 minimum up (so every tile geometry of k_track_gn -- 64 / 32 / 16-column 2-D tiles, raster tiles, partial last tiles),
+    level indices (step size, the level-2 crop), pixels per thread / gather groups, sprinkled INVALID gray, zero / sub-gate / NaN
+    depth, both sigma clamps, and poses from a fraction of a pixel to far outside the image.  Per case: contributing-pixel masks and
+    counts bit-exact, H / g / update within the tolerances of tests/util.py."""
+    rng = np.random.RandomState(20260410)
+    sizes = [(4, 4), (5, 7), (16, 9), (33, 17), (64, 16), (64, 40), (96, 50), (128, 33), (48, 96), (161, 121), (200, 37), (31, 200)]
+    variants = [(1, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 2)]
+    checked = contributing = 0
+    for case in range(36):
+        w, h = sizes[case % len(sizes)]
+        level = int(rng.randint(0, 4))
+        ppt, grp = variants[int(rng.randint(len(variants)))]
+        crop = bool(rng.randint(2))
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        ph = rng.uniform(0, 6.28, size=4)
+        tex = lambda sx, sy: (0.5 + 0.22 * np.sin(0.35 * (xx + sx) + ph[0]) * np.cos(0.27 * (yy + sy) + ph[1])
+                              + 0.15 * np.sin(0.11 * (xx + sx) * 0.9 + 0.13 * (yy + sy) + ph[2])).astype(np.float32)
+        rg, og = tex(0.0, 0.0), tex(float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.8, 0.8)))
+        og = (og + 0.01 * rng.standard_normal(og.shape)).astype(np.float32)
+        rd = (1.2 + 0.4 * np.sin(0.05 * xx + ph[3]) + 0.3 * np.cos(0.07 * yy)).astype(np.float32)
+        rs = rng.choice(np.array([0.003, 0.05, 0.1, 0.3, 0.8], np.float32), size=rd.shape).astype(np.float32)
+        rg[rng.uniform(size=rg.shape) < 0.03] = INV
+        og[rng.uniform(size=og.shape) < 0.03] = INV
+        rd[rng.uniform(size=rd.shape) < 0.04] = 0.0
+        rd[rng.uniform(size=rd.shape) < 0.02] = 0.15
+        if case % 5 == 0:
+            rd[rng.uniform(size=rd.shape) < 0.01] = np.nan
+        f = 0.9 * max(w, h)
+        K = np.array([f, 0, w / 2.0 - 0.3, 0, f, h / 2.0 + 0.2, 0, 0, 1], np.float32)
+        scale = [0.002, 0.01, 0.05, 0.4][case % 4]           # from sub-pixel motion to poses that throw most pixels out of the image
+        xi = (scale * rng.standard_normal(6)).astype(np.float32)
+        cfg = dvo.default_config(crop_enable=1 if crop else 0, gn_pixels_per_thread=ppt, gn_gather_group=grp)
+        o = orc.optimize(og, rg, rd, rs, K, xi, level, crop=crop, want_mask=True)
+        r = dvo.optimize(og, rg, rd, rs, K, xi, level, cfg=cfg, want_mask=True)
+        tag = (case, w, h, level, ppt, grp, crop)
+        np.testing.assert_array_equal(r["mask"], o["mask"], err_msg=str(tag))
+        assert r["n_valid"] == o["n_valid"], tag
+        checked += 1
+        if o["n_valid"] == 0:
+            assert r["residual"] == np.float32(-1) and not r["xi_update"].any(), tag
+            continue
+        contributing += 1
+        np.testing.assert_allclose(r["H"], o["H"], rtol=0, atol=TOL_H_REL * np.abs(o["H"]).max(), err_msg=str(tag))
+        np.testing.assert_allclose(r["g"], o["g"], rtol=0, atol=TOL_H_REL * max(np.abs(o["g"]).max(), 1e-30), err_msg=str(tag))
+        np.testing.assert_allclose(r["sum_r2"], o["sum_r2"], rtol=2e-5, err_msg=str(tag))
+        # the update against the oracle's normal equations, as a backward error: small images give badly conditioned (or singular:
+        # fewer than six pixels) systems, where a forward comparison of the two solutions says nothing
+        H = orc.upper_to_full(o["H"]); x = r["xi_update"].astype(np.float64)
+        back = np.abs(H @ x - o["g"]).max() / max((np.abs(H) @ np.abs(x) + np.abs(o["g"])).max(), 1e-300)
+        assert back <= 2e-5, (tag, back)
+    assert checked == 36 and contributing >= 20
+
+
+def test_randomized_propagate_and_regularize_sweep():
+    """Fixed-seed sweep of Implement::propagate (implement.cpp:217-256) and Implement::regularize (implement.cpp:156-180) over
+    ragged sizes from 4 x 4 up, with INVALID / zero / huge depth, both fusion outcomes, ages 0..9 and motions from none to strong
+    forward motion (scatter collisions): depth, sigma and age bit-exact."""
+    rng = np.random.RandomState(777)
+    sizes = [(4, 4), (7, 5), (16, 16), (33, 9), (40, 30), (64, 17), (97, 61), (160, 120), (161, 3 * 41), (255, 8)]
+    for case in range(30):
+        w, h = sizes[case % len(sizes)]
+        depth = rng.normal(1.5, 0.5, (h, w)).astype(np.float32)
+        sigma = (np.abs(rng.normal(0.3, 0.2, (h, w))) + 0.01).astype(np.float32)
+        depth[rng.uniform(size=depth.shape) < 0.05] = INV
+        depth[rng.uniform(size=depth.shape) < 0.05] = 0.0
+        depth[rng.uniform(size=depth.shape) < 0.02] = 9.0
+        sigma[rng.uniform(size=sigma.shape) < 0.03] = INV
+        if case % 6 == 0:
+            sigma[:] = 0.5                                                  # uniform map: every fusion is accepted or every one rejected
+        np.testing.assert_array_equal(dvo.Implement.regularize(depth, sigma), orc.regularize(depth, sigma), err_msg="regularize %d %dx%d" % (case, w, h))
+        age = rng.randint(0, 10, depth.shape).astype(np.float32)
+        f = 0.9 * max(w, h)
+        K = np.array([f, 0, w / 2.0 + 0.1, 0, f, h / 2.0 - 0.2, 0, 0, 1], np.float32)
+        xi = ([0.0, 0.0, 0.0, 0.0, 0.0, 0.0] if case % 5 == 0 else
+              (np.array([0.02, 0.02, 0.25, 0.03, 0.03, 0.05]) * rng.standard_normal(6)).tolist())
+        xi = np.array(xi, np.float32)
+        dpos = np.where(depth > 0, depth, 1.0).astype(np.float32) if case % 3 == 0 else depth   # (with and without unusable source pixels)
+        got = dvo.Implement.propagate(dpos, sigma, age, xi, K)
+        exp = orc.propagate(dpos, sigma, age, xi, K)
+        for name, a, b in zip(("depth", "sigma", "age"), got, exp):
+            np.testing.assert_array_equal(a, b, err_msg="propagate %s %d %dx%d" % (name, case, w, h))
