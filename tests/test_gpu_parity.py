@@ -640,3 +640,40 @@ def test_randomized_propagate_and_regularize_sweep():
         exp = orc.propagate(dpos, sigma, age, xi, K)
         for name, a, b in zip(("depth", "sigma", "age"), got, exp):
             np.testing.assert_array_equal(a, b, err_msg="propagate %s %d %dx%d" % (name, case, w, h))
+
+
+@pytest.mark.parametrize("seed,w,h,gain,sig,young", [(1, 640, 480, 20.0, 0.3, 0.5), (2, 640, 480, 20.0, 0.2, 0.9), (5, 640, 480, 40.0, 0.5, 0.0),
+                                                     (6, 640, 480, 30.0, 0.4, 0.3), (9, 648, 488, 25.0, 0.3, 0.5)])
+def test_mapper_update_sweep(seed, w, h, gain, sig, young):
+    """Mapper::update / Implement::update (mapper.cpp:76-137, implement.cpp:23-152,182-214) on three keyframes over baselines from
+    short (few search steps) to long (the 102-step cap), a map size that is no multiple of the workgroup's pixel count, prior sigmas
+    from 0.2 to the 0.5 clamp and age maps from 'all born in the newest keyframe' to 'all born in the oldest': depth, sigma, age and
+    the valid-update count bit-exact."""
+    K = np.array(K640, np.float32).copy()
+    K[0] *= w / 640.0; K[1] *= h / 480.0
+    from dvo_amd import synth
+    g, d, s, poses = synth.sequence(6, width=w, height_px=h, K=K, seed=30 + seed, sigma_value=0.5)
+    g, d = g.numpy(), d.numpy()
+    rng = np.random.RandomState(100 + seed)
+    kfs = [orc.OFrame(g[i], d[i], np.full_like(d[i], 0.5), K, 3, 2, id=i) for i in (0, 1, 3)]
+    obj = orc.OFrame(g[4], None, None, K, 3, 2, id=4)
+    def twist(a, b):
+        return orc.se3_log((np.linalg.inv(poses[b]) @ poses[a]).astype(np.float32)) * np.float32(gain)
+    x1 = twist(0, 1); x3 = orc.se3_concatenate(x1, twist(1, 3)); rel = twist(3, 4)
+    kfs[1].set_pose(x1, x1); kfs[2].set_pose(x3, twist(1, 3)); obj.set_pose(orc.se3_concatenate(x3, rel), rel)
+    ref = kfs[2]
+    top_d = (ref.depth(2) + rng.normal(0, 0.05, ref.depth(2).shape)).astype(np.float32)
+    top_d[rng.uniform(size=top_d.shape) < 0.03] = 0.05                      # below every gate
+    top_s = np.full_like(top_d, sig)
+    u = rng.uniform(size=top_d.shape)
+    age = np.where(u < young, 0.0, np.where(u < young + (1 - young) / 2, 1.0, 2.0)).astype(np.float32)
+    ref.update_depth_sigma(top_d, top_s)
+    ref.set_age(age)
+    got_d, got_s, got_a, got_v = dvo.mapper_update([k.gray(2) for k in kfs], [k.xi for k in kfs], obj.gray(2), obj.xi, obj.rel_xi, 4,
+                                                   ref.K(2), top_d, top_s, age, cfg=dvo.default_config(rng_seed=seed))
+    v = orc.mapper_update(kfs, obj, seed)
+    np.testing.assert_array_equal(got_a, ref.age())
+    np.testing.assert_array_equal(got_d, ref.depth(2))
+    np.testing.assert_array_equal(got_s, ref.sigma(2))
+    assert got_v == v
+    assert (got_d != top_d).sum() > 100, ((got_d != top_d).sum(), got_v)   # the case really exercised the update (oracle: 222 .. 2376 pixels)
