@@ -125,7 +125,7 @@ def main():
             a.fixed_iters = 10
     if a.batch <= 0:
         # the latency-bound parts of a step (coarse levels, solves, the tail of each level) amortise over more sequences per launch:
-        # 251 k / 263 k / 270 k frames/s at 4096 / 8192 / 16384.  16384 raw sequences = 90 GB of input frames + 100 GB of pyramids.
+        # 251 k / 263 k / 270 k frames/s at 4096 / 8192 / 16384.  16384 raw sequences = 90 GB of input frames + 80 GB of pyramids.
         a.batch = (16384 if (a.input == "raw" and abs(a.sigma - 0.1) < 1e-9) else 4096) if a.workload == "syn640" else 128
     B, F = a.batch, max(2, a.frames)
 
@@ -487,7 +487,7 @@ def main_mono(a, rank, local, world, dev, cdev, rehearse):
     if world > 1:
         import torch.distributed as dist
     W, H, K = 640, 480, synth.K_640
-    B = a.batch if a.batch > 0 else 4096
+    B = a.batch if a.batch > 0 else 8192   # 1.43 M / 1.51 M / 1.52 M frames/s at 4096 / 8192 / 16384 sequences (round 2)
     F = max(2, a.frames)
     t_gen = time.time()
     raw = a.input == "raw"
