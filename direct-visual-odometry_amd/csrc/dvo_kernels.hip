@@ -1,6 +1,6 @@
 // dvo_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the direct-VO hot path.
 //
-// wave64, 256-thread workgroups, no MFMA (the path is HBM/VALU-bound image warping).
+// wave64, 256-thread workgroups, no MFMA (image warping bound by the vector ALUs and the L1 gather path).
 // Reductions are fixed-order (DPP row_shr / row_bcast inside a wave, LDS across the 4 waves, double
 // across workgroups) so every run is bit-reproducible.  Built with -ffp-contract=off: only the fmaf()
 // calls written in dvo_math.h fuse.
@@ -318,8 +318,11 @@ __global__ void __launch_bounds__(256) k_warp_image(const float* __restrict__ gr
 // k_track_gn: the fused Gauss-Newton accumulation = Transform::warpImage + Track::optimize's per-pixel
 // lambda (optimize.cpp:28-90) + the A^T A / A^T B products that cv::solve's SVD stands for.
 //
-// HBM traffic per evaluated pixel: obj_gray 4 + ref_depth 4 + ref_sigma 4 (coalesced rows) + ref_gray 4
-// (12-tap plus-shaped gather around the warped position, served by L1/L2 or the LDS patch) = 16 B.
+// HBM traffic per evaluated pixel, by contract: obj_gray 4 + ref_depth 4 + ref_sigma 4 (coalesced rows) + ref_gray 4
+// (12-tap plus-shaped gather around the warped position, served by L1/L2 or the LDS patch) = 16 B.  Read in fact: the weight map
+// step / clamp(sigma) in place of sigma -- or nothing at all for raw sensor frames, whose contributing pixels share one weight
+// (GnArgs::wgt_const) -- and 1 / depth recomputed (recip_gated): 12-13 B.  Through the L1 it is 56 B per lane and pixel (8 B of rows,
+// 48 B of taps), and that path, 78 % busy, limits the kernel together with the vector ALUs.
 // Each thread owns PPT pixels (stride 256 => coalesced), keeps 29 accumulators (21 upper-tri J^T J, 6 J^T wr,
 // sum r^2, count), then: DPP wave sum -> LDS across the 4 waves -> one 32-float partial per workgroup.
 // ------------------------------------------------------------------------------------------------

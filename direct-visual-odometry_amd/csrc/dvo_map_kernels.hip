@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_regularize(const float* __restrict__ de
 // k_regularize_redecimate: k_regularize and the re-decimation that follows it in the mono pipeline, one pass.  Same operations per
 // pixel as k_regularize + k_pyramid(culls = 0, depth and sigma): the regularized value is written to a second top-level buffer (the
 // 5-point stencil of the neighbours still reads the old one) and decimated on the spot into every level it lands on, with sigma,
-// 1/depth and the Gauss-Newton weight -- saves one launch and the 8 B/px round trip of the intermediate map.
+// and the Gauss-Newton weight -- saves one launch and the 8 B/px round trip of the intermediate map.
 __global__ void __launch_bounds__(256) k_regularize_redecimate(RegDecArgs a)
 {
     const int T = a.levels - 1, w = a.w[T], h = a.h[T];

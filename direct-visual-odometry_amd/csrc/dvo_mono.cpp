@@ -182,7 +182,7 @@ int MonoBatch::odometrize(const FrameInput& in)
         launch_mono_commit(m, hist_xi.as<float>(), n_seq, R, 0, frame_id, nullptr, nullptr, nullptr, stream);
     }
     // Mapper::regularize (mapper.cpp:139-144) of the newest keyframe, then Frame::updateDepthSigma / updateDepth (frame.cpp:39-61):
-    // every level of depth and sigma is a decimation of the top maps, so ONE pass re-derives both pyramids (and 1/depth, the
+    // every level of depth and sigma is a decimation of the top maps, so ONE pass re-derives both pyramids (and the
     // weight) from the regularized depth and the current sigma -- the same values the reference's two re-decimations leave.
     {
         RegDecArgs ra;
