@@ -586,6 +586,8 @@ def test_randomized_gn_step_sweep():
         rd[rng.uniform(size=rd.shape) < 0.02] = 0.15
         if case % 5 == 0:
             rd[rng.uniform(size=rd.shape) < 0.01] = np.nan
+        if case % 7 == 3:
+            rd[rng.uniform(size=rd.shape) < 0.02] = np.float32(3e30)    # beyond 2^100: the IEEE-division branch of recip_gated / recip_rn
         f = 0.9 * max(w, h)
         K = np.array([f, 0, w / 2.0 - 0.3, 0, f, h / 2.0 + 0.2, 0, 0, 1], np.float32)
         scale = [0.002, 0.01, 0.05, 0.4][case % 4]           # from sub-pixel motion to poses that throw most pixels out of the image
