@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SIG=${1:-0.5}; PPT=${2:-0}; GRP=${3:-0}; B=${4:-64}
 cd /tmp && export TMPDIR=/tmp
 OUT=/tmp/pmc_$$
-ARGS="--batch $B --level 3 --launches 4 --sigma $SIG --ppt $PPT --group $GRP"
+ARGS="--batch $B --level 3 --launches 4 --sigma $SIG --ppt $PPT --group $GRP $PROBE_EXTRA"
 i=0
 for SET in \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS" \

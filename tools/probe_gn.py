@@ -23,6 +23,7 @@ ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--lds", type=int, default=-1, help="-1 auto, 0 global gathers, N>0 LDS patch margin")
 ap.add_argument("--distinct", type=int, default=4, help="distinct rendered sequences (tiled to --batch)")
+ap.add_argument("--raw", action="store_true", help="feed raw u8 gray + u16 depth frames (sigma 0.1: constant weight, no wgt map) instead of float maps")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 W, H, K = 640, 480, synth.K_640
@@ -39,8 +40,15 @@ sigma = torch.full_like(gray, a.sigma)
 torch.cuda.synchronize()
 cfg = dvo.default_config(stream=torch.cuda.current_stream().cuda_stream, gn_pixels_per_thread=a.ppt, gn_gather_group=a.group, gn_use_lds_patch=a.lds)
 bt = dvo.Batch(a.batch, K, W, H, 4, 1, cfg=cfg)
+if a.raw:
+    g8 = (gray.clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
+    d16 = (depth.clamp(0, 13) * 5000).round().to(torch.int32).to(torch.int16).contiguous()   # (bit pattern of the u16 value)
+    torch.cuda.synchronize()
 for f in range(2):
-    bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
+    if a.raw:
+        bt.push_raw_device(g8[f].data_ptr(), 1, d16[f].data_ptr())
+    else:
+        bt.push_device(gray[f].data_ptr(), depth[f].data_ptr(), sigma[f].data_ptr())
 bt.synchronize()
 for lvl in ([a.level] if a.level >= 0 else range(4)):
     ms, px = bt.probe_gn(lvl, a.launches)
