@@ -274,6 +274,14 @@ struct MonoBatch {
     int n_host = 0;
     bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // as Batch::decimate_host_rows
     int top_pixels() const { return g.w[g.top()] * g.h[g.top()]; }
+    // profiling of the mapping stages (cfg.profile): hipEvent pairs on `stream` around k_depth_update (+ k_age_table),
+    // k_regularize_redecimate and the three k_propagate_* passes of every frame
+    struct MapEv { hipEvent_t e[6]; };
+    std::vector<MapEv> map_ev;
+    size_t map_ev_used = 0;
+    double prof_update_ms = 0, prof_regularize_ms = 0, prof_propagate_ms = 0;
+    uint64_t prof_frames = 0;
+    int collect_map_profile();
 };
 
 void default_initial_depth(int n, uint32_t seed, std::vector<float>& d, std::vector<float>& s);

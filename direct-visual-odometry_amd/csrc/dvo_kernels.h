@@ -173,7 +173,8 @@ struct MonoSeq {          // Mapper + FrameHistory state of one sequence (mapper
     int   frame_id;
     int   need;           // Mapper::needNewFrame (mapper.cpp:45-60) of this frame
     int   valid_updates;  // "valid update: N pixel", mapper.cpp:136
-    int   pad;
+    int   clamped;        // cumulative: pixels whose age pointed past the keyframe ring and were searched against the oldest retained
+                          // keyframe instead (UpdateArgs::clamp_age; 0 for a history that holds every keyframe, as the reference's)
 };
 
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)

@@ -915,6 +915,8 @@ __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, S
         lg.n_valid[a.level][it] = n_valid;
 #pragma unroll
         for (int i = 0; i < 6; i++) lg.xi_after[a.level][it][i] = xi[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) lg.xi_update[a.level][it][i] = upd[i];
     }
     if (a.result) {  // operator-level output (dvo_op_gn_step)
         dvo_gn_result& r = a.result[seq];

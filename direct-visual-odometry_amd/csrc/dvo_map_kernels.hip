@@ -301,7 +301,10 @@ __device__ __forceinline__ int depth_update_head(const UpdateArgs& a, const int 
     if (qx < 0 || w <= qx || qy < 0 || h <= qy) return 0;
     const int age = (int)a.ref_age[base + i];                          // mapper.cpp:99
     int bi = n_hist - 1 - age;                                         // frame.hpp:176
-    if (bi < 0 && a.clamp_age) bi = 0;
+    if (bi < 0 && a.clamp_age) {   // (rare: only once a sequence has created more than R keyframes and a pixel survived them all)
+        bi = 0;
+        if (m) atomicAdd(const_cast<int*>(&m->clamped), 1);
+    }
     if (bi < 0 || bi >= n_hist) return 0;
     const AgeEntry& born = a.ages[(size_t)seq * a.R + bi];
     const float depth = d - rel_tz;                                    // mapper.cpp:104

@@ -19,7 +19,24 @@ MonoBatch::~MonoBatch()
         if (st.copied) (void)hipEventDestroy(st.copied);
         if (st.consumed) (void)hipEventDestroy(st.consumed);
     }
+    for (auto& m : map_ev)
+        for (hipEvent_t e : m.e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+int MonoBatch::collect_map_profile()
+{
+    DVO_HIP(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < map_ev_used; i++) {
+        float p = 0, u = 0, r = 0;
+        DVO_HIP(hipEventElapsedTime(&p, map_ev[i].e[0], map_ev[i].e[1]));
+        DVO_HIP(hipEventElapsedTime(&u, map_ev[i].e[2], map_ev[i].e[3]));
+        DVO_HIP(hipEventElapsedTime(&r, map_ev[i].e[4], map_ev[i].e[5]));
+        prof_propagate_ms += p; prof_update_ms += u; prof_regularize_ms += r;
+        prof_frames++;
+    }
+    map_ev_used = 0;
+    return DVO_OK;
 }
 
 int MonoBatch::init(int n, const float K9[9], int w, int h, int ring, const dvo_config* c)
@@ -89,7 +106,6 @@ int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
     }
     trk.adaptive = false;   // (the host must not be held inside track(): the next frame's transfer is queued meanwhile)
     Stage& st = stage[n_host & 1];
-    n_host++;
     if (st.buf.bytes < bytes) DVO_TRY(st.buf.alloc(bytes));
     if (st.used) DVO_HIP(hipStreamWaitEvent(cstream, st.consumed, 0));
     if (in.raw()) {  // only the rows the pyramid keeps cross PCIe (Batch::push_host_frame)
@@ -104,9 +120,14 @@ int MonoBatch::odometrize_host(const void* frames, size_t bytes, FrameInput in)
     DVO_HIP(hipStreamWaitEvent(stream, st.copied, 0));
     if (in.raw()) in.rgb = st.buf.as<uint8_t>(); else in.gray = st.buf.as<float>();
     const int rc = odometrize(in);
+    if (rc != DVO_OK) {   // the frame was not consumed: same staging slot next time, once whatever was queued has drained
+        (void)hipStreamSynchronize(stream);
+        return rc;
+    }
     DVO_HIP(hipEventRecord(st.consumed, stream));
     st.used = true;
-    return rc;
+    n_host++;
+    return DVO_OK;
 }
 
 int MonoBatch::odometrize(const FrameInput& in)
@@ -116,7 +137,9 @@ int MonoBatch::odometrize(const FrameInput& in)
     gin.depth = nullptr; gin.sigma = nullptr; gin.depth16 = nullptr;
     DVO_TRY(select_device(device));
     const int T = g.top(), tw = g.w[T], th = g.h[T], np = tw * th;
-    const int frame_id = ++latest_id;
+    // Frame::latest_id (frame.cpp:5) advances only once the frame's launches were queued: a call that fails leaves the batch where it
+    // was (a failed first frame leaves it not started), so frame ids -- and with them keyframe_max_frames -- never shift
+    const int frame_id = latest_id + 1;
     MonoSeq* m = meta.as<MonoSeq>();
     if (frame_id == 0) {  // system.hpp:49-54: the first frame is the first keyframe of every sequence
         if (!have_init) {
@@ -134,7 +157,17 @@ int MonoBatch::odometrize(const FrameInput& in)
         launch_promote(pa, stream);
         launch_mono_commit(m, hist_xi.as<float>(), n_seq, R, 1, frame_id, xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), stream);
         DVO_HIP(hipGetLastError());
+        latest_id = frame_id;
         return DVO_OK;
+    }
+    MapEv* pe = nullptr;
+    if (cfg.profile) {
+        if (map_ev_used == map_ev.size()) {
+            MapEv m6;
+            for (hipEvent_t& e : m6.e) DVO_HIP(hipEventCreate(&e));
+            map_ev.push_back(m6);
+        }
+        pe = &map_ev[map_ev_used];
     }
     { TraceRange tr("mono pyramid"); build_pyramid(frm, gin, stream); }           // Frame(gray, K, 3, 2)
     { TraceRange tr("mono track"); DVO_TRY(trk.track(frm, ref, stream)); }           // system.hpp:57
@@ -149,11 +182,14 @@ int MonoBatch::odometrize(const FrameInput& in)
         a.owner = owner.as<int>();
         a.w = tw; a.h = th; a.n_seq = n_seq; a.k = g.k[T]; a.meta = m;
         memset(&a.pose, 0, sizeof a.pose); a.tz = 0.0f;
+        if (pe) DVO_HIP(hipEventRecord(pe->e[0], stream));
         launch_propagate_batch(a, stream);
+        if (pe) DVO_HIP(hipEventRecord(pe->e[1], stream));
     }
     {   // !need: stereo update of the reference maps against the keyframe each pixel was born in (mapper.cpp:76-137)
         AgeTableArgs ta;
         ta.meta = m; ta.hist_xi = hist_xi.as<float>(); ta.ages = ages.as<AgeEntry>(); ta.n_seq = n_seq; ta.R = R; ta.n_hist = -1;
+        if (pe) DVO_HIP(hipEventRecord(pe->e[2], stream));
         launch_age_table(ta, stream);
         UpdateArgs a;
         memset(&a, 0, sizeof a);
@@ -167,6 +203,7 @@ int MonoBatch::odometrize(const FrameInput& in)
         a.k = g.k[T];
         memcpy(a.K9, g.K9[T], sizeof a.K9);
         launch_depth_update(a, stream);
+        if (pe) DVO_HIP(hipEventRecord(pe->e[3], stream));
     }
     {   // ... need: the frame becomes the newest keyframe (FrameHistory::push, frame.hpp:151-157)
         PromoteArgs pa;
@@ -196,10 +233,13 @@ int MonoBatch::odometrize(const FrameInput& in)
             ra.step[l] = ref.step[l];
         }
         ra.levels = g.levels; ra.n_seq = n_seq; ra.sigma_min = ref.sigma_min; ra.sigma_max = ref.sigma_max;
+        if (pe) DVO_HIP(hipEventRecord(pe->e[4], stream));
         launch_regularize_redecimate(ra, stream);
+        if (pe) { DVO_HIP(hipEventRecord(pe->e[5], stream)); map_ev_used++; }
         std::swap(ref.depth[T], depth_alt);   // the top-level depth map alternates between the arena block and `tmp`
     }
     DVO_HIP(hipGetLastError());
+    latest_id = frame_id;
     return DVO_OK;
 }
 
@@ -322,6 +362,45 @@ int dvo_batch_keyframe_get(dvo_batch* b, int seq, int level, float* gray, float*
     if (id) *id = m.ref_id;
     if (n_keyframes) *n_keyframes = m.n_total;
     if (valid_updates) *valid_updates = m.valid_updates;
+    return DVO_OK;
+}
+
+int dvo_batch_mono_stats(dvo_batch* b, int seq, dvo_mono_stats* out)
+{
+    DVO_NEED_MONO(b);
+    MonoBatch& M = *b->mono;
+    if (!out || seq < 0 || seq >= M.n_seq) return DVO_ERR_BAD_ARGUMENT;
+    if (M.latest_id < 0) return DVO_ERR_NOT_READY;
+    DVO_TRY(select_device(M.device));
+    MonoSeq m;
+    DVO_HIP(hipMemcpyAsync(&m, M.meta.as<MonoSeq>() + seq, sizeof m, hipMemcpyDeviceToHost, M.stream));
+    DVO_HIP(hipStreamSynchronize(M.stream));
+    out->frames = M.latest_id + 1;
+    out->keyframes_created = m.n_total;
+    out->ring_keyframes = M.R;
+    out->valid_updates_last_frame = m.valid_updates;
+    out->clamped_pixels = m.clamped;
+    return DVO_OK;
+}
+
+int dvo_batch_profile_mapping(dvo_batch* b, dvo_map_profile* out, int reset)
+{
+    DVO_NEED_MONO(b);
+    MonoBatch& M = *b->mono;
+    if (!out) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(M.device));
+    DVO_TRY(M.collect_map_profile());
+    out->frames = M.prof_frames;
+    out->depth_update_ms = M.prof_update_ms;
+    out->regularize_ms = M.prof_regularize_ms;
+    out->propagate_ms = M.prof_propagate_ms;
+    const int T = M.g.top(), w = M.g.w[T], h = M.g.h[T];
+    // the window of mapper.cpp:90 (cols 16..144, rows 12..108 at 160x120) when crop_enable, else the whole map
+    const int cx = M.cfg.crop_enable ? ((w - 1 < 144 ? w - 1 : 144) - 16 + 1) : w, cy = M.cfg.crop_enable ? ((h - 1 < 108 ? h - 1 : 108) - 12 + 1) : h;
+    const int wx = cx > 0 ? cx : 0, wy = cy > 0 ? cy : 0;   // (as launch_depth_update)
+    out->update_window_pixels = (uint64_t)wx * wy * (uint64_t)M.n_seq;
+    out->map_pixels = (uint64_t)w * h * (uint64_t)M.n_seq;
+    if (reset) { M.prof_frames = 0; M.prof_update_ms = M.prof_regularize_ms = M.prof_propagate_ms = 0; }
     return DVO_OK;
 }
 

@@ -22,6 +22,10 @@ class DvoError(RuntimeError):
     pass
 
 
+# status codes of include/dvo.h
+DVO_OK, DVO_ERR_BAD_ARGUMENT, DVO_ERR_HIP, DVO_ERR_NO_DEVICE, DVO_ERR_NO_VALID_PIXELS, DVO_ERR_NOT_READY, DVO_ERR_OUT_OF_MEMORY = range(7)
+
+
 class Config(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("min_update", C.c_float), ("min_residual", C.c_float),
                 ("fixed_iterations", C.c_int), ("crop_enable", C.c_int), ("step_default", C.c_float),
@@ -38,13 +42,15 @@ class TrackLog(C.Structure):
                 ("residual", (C.c_float * MAX_ITERATIONS) * MAX_LEVELS),
                 ("update_norm", (C.c_float * MAX_ITERATIONS) * MAX_LEVELS),
                 ("n_valid", (C.c_int * MAX_ITERATIONS) * MAX_LEVELS),
-                ("xi_after", ((C.c_float * 6) * MAX_ITERATIONS) * MAX_LEVELS)]
+                ("xi_after", ((C.c_float * 6) * MAX_ITERATIONS) * MAX_LEVELS),
+                ("xi_update", ((C.c_float * 6) * MAX_ITERATIONS) * MAX_LEVELS)]
 
     def to_dict(self):
         L = self.levels
-        out = dict(n_iter=[self.n_iter[l] for l in range(L)], residual=[], upd_norm=[], n_valid=[], xi_after=[])
+        out = dict(n_iter=[self.n_iter[l] for l in range(L)], residual=[], upd_norm=[], n_valid=[], xi_after=[], xi_update=[])
         for l in range(L):
             n = self.n_iter[l]
+            out["xi_update"].append(np.array([self.xi_update[l][i][:] for i in range(n)], np.float32).reshape(n, 6))
             out["residual"].append(np.array(self.residual[l][:n], np.float32))
             out["upd_norm"].append(np.array(self.update_norm[l][:n], np.float32))
             out["n_valid"].append(np.array(self.n_valid[l][:n], np.int32))
@@ -62,6 +68,16 @@ class GnProfile(C.Structure):
                 ("gn_iterations", C.c_uint64)]
 
 
+class MonoStats(C.Structure):
+    _fields_ = [("frames", C.c_int), ("keyframes_created", C.c_int), ("ring_keyframes", C.c_int),
+                ("valid_updates_last_frame", C.c_int), ("clamped_pixels", C.c_int)]
+
+
+class MapProfile(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("depth_update_ms", C.c_double), ("regularize_ms", C.c_double), ("propagate_ms", C.c_double),
+                ("update_window_pixels", C.c_uint64), ("map_pixels", C.c_uint64)]
+
+
 EXPORTS = [
     "dvo_config_default", "dvo_version", "dvo_status_string", "dvo_last_error", "dvo_device_count",
     "dvo_vo_create", "dvo_vo_destroy", "dvo_vo_set_initial_depth", "dvo_vo_init_keyframe", "dvo_vo_odometrize",
@@ -72,7 +88,7 @@ EXPORTS = [
     "dvo_batch_push_raw_device", "dvo_batch_prefetch_raw_device", "dvo_batch_push_raw_host", "dvo_batch_odometrize_raw_device",
     "dvo_batch_odometrize_host", "dvo_batch_odometrize_raw_host",
     "dvo_batch_create_mono", "dvo_batch_set_initial_depth", "dvo_batch_set_initial_depth_device", "dvo_batch_odometrize_device",
-    "dvo_batch_world_poses", "dvo_batch_copy_world_poses_device", "dvo_batch_keyframe_get",
+    "dvo_batch_world_poses", "dvo_batch_copy_world_poses_device", "dvo_batch_keyframe_get", "dvo_batch_mono_stats", "dvo_batch_profile_mapping",
     "dvo_op_cull_image", "dvo_op_gradient", "dvo_op_warp_image", "dvo_op_pyramid", "dvo_op_gn_step", "dvo_op_track",
     "dvo_op_propagate", "dvo_op_regularize", "dvo_op_depth_update", "dvo_op_se3_exp", "dvo_op_se3_log",
     "dvo_op_se3_concatenate",
@@ -620,6 +636,18 @@ class MonoBatch:
 
     def synchronize(self):
         _check(lib().dvo_batch_synchronize(self._p))
+
+    def stats(self, seq):
+        """per-sequence counters (dvo_mono_stats): frames, keyframes created, ring size, valid updates of the last frame and the
+        cumulative number of pixels whose birth keyframe had left the ring (searched against the oldest retained one instead)"""
+        st = MonoStats()
+        _check(lib().dvo_batch_mono_stats(self._p, seq, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in MonoStats._fields_}
+
+    def profile_mapping(self, reset=False):
+        p = MapProfile()
+        _check(lib().dvo_batch_profile_mapping(self._p, C.byref(p), 1 if reset else 0))
+        return {k: getattr(p, k) for k, _ in MapProfile._fields_}
 
     def profile(self, reset=False):
         p = GnProfile()

@@ -112,6 +112,7 @@ typedef struct dvo_track_log {
     float update_norm[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS];
     int   n_valid[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS];
     float xi_after[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS][6];
+    float xi_update[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS][6];  /* Outcome::xi_update of the iteration (optimize.cpp:98), before the composition */
 } dvo_track_log;
 int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log);
 
@@ -200,6 +201,28 @@ int dvo_batch_copy_world_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_
  * only), its world twist, id, the number of keyframes the sequence has created and the valid-update count of the last frame */
 int dvo_batch_keyframe_get(dvo_batch* b, int seq, int level, float* gray, float* depth, float* sigma, float* age, float xi[6], int* id,
                            int* n_keyframes, int* valid_updates);
+/* Per-sequence counters of a mono batch.  `clamped_pixels` makes the one deviation of the ring from the reference's unbounded
+ * FrameHistory (frame.hpp:146-188) visible: a pixel older than the `ring_keyframes` retained keyframes is searched against the
+ * oldest retained one instead of the keyframe it was born in (mapper.cpp:99-101, frame_history[age]); the count is cumulative and
+ * stays 0 until a sequence has created more than `ring_keyframes` keyframes AND a pixel has survived all of them. */
+typedef struct dvo_mono_stats {
+    int frames;                    /* frames consumed (Frame::latest_id + 1) */
+    int keyframes_created;
+    int ring_keyframes;
+    int valid_updates_last_frame;  /* mapper.cpp:136 */
+    int clamped_pixels;
+} dvo_mono_stats;
+int dvo_batch_mono_stats(dvo_batch* b, int seq, dvo_mono_stats* out);
+/* Profile of the mapping stages (cfg.profile = 1): hipEvent-bracketed durations on the handle's stream, summed over the frames
+ * since the last reset.  depth_update = k_age_table + k_depth_update (Mapper::update), regularize = k_regularize_redecimate
+ * (Mapper::regularize + Frame::updateDepth*), propagate = the three k_propagate_* passes (Mapper::propagate). */
+typedef struct dvo_map_profile {
+    uint64_t frames;
+    double   depth_update_ms, regularize_ms, propagate_ms;
+    uint64_t update_window_pixels;   /* pixels one k_depth_update launch covers (window of mapper.cpp:90 x n_seq) */
+    uint64_t map_pixels;             /* top-level pixels x n_seq (one k_regularize_redecimate launch) */
+} dvo_map_profile;
+int dvo_batch_profile_mapping(dvo_batch* b, dvo_map_profile* out, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Operator level (host pointers): each runs the corresponding HIP kernel once.  Used by the parity

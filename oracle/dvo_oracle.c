@@ -22,6 +22,20 @@ static int g_threads = 1;
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
 int  orc_get_threads(void) { return g_threads; }
 
+/* Arithmetic mode (test instrumentation for deviations D8 / D2).  0 (default) = the canonical order the product
+ * shares (shared reciprocals, explicit fmaf chains, SE(3) in double).  ORC_LIT_ARITH: every per-pixel expression exactly as the
+ * source text writes it -- true divisions, no shared reciprocal, no fused multiply-add, left-to-right float evaluation
+ * (transform.cpp:20-28, optimize.cpp:67-77, convert.cpp:103-104, gaussian.cpp:28, implement.cpp:85,245-246).  ORC_LIT_SE3: the
+ * per-pixel pose and the pose composition from the float-literal restatement of se3.cpp (orc_se3_*_f32lit).  Only the
+ * sensitivity tests and bench.py's oracle_self_sensitivity leg set it; never concurrently with running oracle calls. */
+static int g_lit = 0;
+void orc_set_literal(int mask) { g_lit = mask & (ORC_LIT_ARITH | ORC_LIT_SE3); }
+int  orc_get_literal(void) { return g_lit; }
+/* Sensitivity probe: orc_track moves the first component of the first xi_update (level 0, iteration 0) by n units in the last place.
+ * 0 = off.  A 1-ulp nudge is below anything two correct implementations can be expected to share. */
+static int g_nudge = 0;
+void orc_set_nudge_ulps(int n) { g_nudge = n; }
+
 /* ------------------------------------------------------------------------ */
 /* include/math/util.hpp:6-32                                                */
 static inline int is_valid(float v) { return ORC_INVALID < v; }
@@ -140,8 +154,19 @@ void orc_se3_concatenate(const float a[6], const float b[6], float out[6])
     for (int i = 0; i < 6; i++) out[i] = (float)x[i];
 }
 
+void orc_se3_exp_f32lit(const float xi[6], float T[16]);
 void orc_pose_from_xi(const float xi[6], float sign, float Rt[12])
 {
+    if (g_lit & ORC_LIT_SE3) { /* transform.cpp:13-14: transform(se3::exp(cv::Mat1f(-xi)), x), exp in float (se3.cpp:70-98) */
+        float xs[6], T[16];
+        for (int i = 0; i < 6; i++) xs[i] = sign * xi[i];
+        orc_se3_exp_f32lit(xs, T);
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) Rt[3 * r + c] = T[4 * r + c];
+            Rt[9 + r] = T[4 * r + 3];
+        }
+        return;
+    }
     double x[6], R[9], t[3];
     for (int i = 0; i < 6; i++) x[i] = (double)sign * (double)xi[i];
     se3_exp_d(x, R, t);
@@ -309,6 +334,8 @@ void orc_gradiate(const float* img, int w, int h, int xdir, float* out)
 /* bilinear blend in the fixed order of DESIGN.md §3 (D8) */
 static inline float blend4(const float g[4], float hx, float vy)
 {
+    if (g_lit & ORC_LIT_ARITH) /* convert.cpp:103-104, 175-176 as written */
+        return (g[0] * (1.f - hx) + g[1] * hx) * (1.f - vy) + (g[2] * (1.f - hx) + g[3] * hx) * vy;
     const float omh = 1.0f - hx, omv = 1.0f - vy;
     const float top = fmaf(g[1], hx, g[0] * omh);
     const float bot = fmaf(g[3], hx, g[2] * omh);
@@ -364,6 +391,12 @@ float orc_get_subpixel(const float* img, int w, int h, float px, float py)
 void orc_back_project(const float K[9], float px, float py, float d, float X[3])
 { /* transform.cpp:25-28: depth * (p - c) / f.  D8: the division by the per-level constant f is a multiplication
    * by its correctly rounded reciprocal (the reference is built -Ofast, i.e. -freciprocal-math) */
+    if (g_lit & ORC_LIT_ARITH) { /* depth * (point.x - K(0,2)) / K(0,0) */
+        X[0] = d * (px - K[2]) / K[0];
+        X[1] = d * (py - K[5]) / K[4];
+        X[2] = d;
+        return;
+    }
     const float ifx = 1.0f / K[0], ify = 1.0f / K[4];
     X[0] = (d * (px - K[2])) * ifx;
     X[1] = (d * (py - K[5])) * ify;
@@ -372,6 +405,11 @@ void orc_back_project(const float K[9], float px, float py, float d, float X[3])
 
 void orc_project(const float K[9], const float X[3], float p[2])
 { /* transform.cpp:20-23; D8: one reciprocal of z shared by both coordinates */
+    if (g_lit & ORC_LIT_ARITH) { /* point.x * K(0,0) / point.z + K(0,2) */
+        p[0] = X[0] * K[0] / X[2] + K[2];
+        p[1] = X[1] * K[4] / X[2] + K[5];
+        return;
+    }
     const float iz = 1.0f / X[2];
     p[0] = (X[0] * K[0]) * iz + K[2];
     p[1] = (X[1] * K[4]) * iz + K[5];
@@ -379,6 +417,11 @@ void orc_project(const float K[9], const float X[3], float p[2])
 
 void orc_transform(const float Rt[12], const float X[3], float Y[3])
 { /* transform.cpp:7-12: R x + t as an fmaf chain (D8) */
+    if (g_lit & ORC_LIT_ARITH) { /* R * cv::Mat(x) + t: a 3x3 by 3x1 float product, row sums left to right in float, then + t
+                                  * (cv::gemm's small-matrix path; Appendix B of SURVEY.md: OpenCV source is not in the tree) */
+        for (int i = 0; i < 3; i++) Y[i] = (Rt[3 * i] * X[0] + Rt[3 * i + 1] * X[1] + Rt[3 * i + 2] * X[2]) + Rt[9 + i];
+        return;
+    }
     for (int i = 0; i < 3; i++)
         Y[i] = fmaf(Rt[3 * i], X[0], fmaf(Rt[3 * i + 1], X[1], fmaf(Rt[3 * i + 2], X[2], Rt[9 + i])));
 }
@@ -575,11 +618,20 @@ void orc_lsq_svd(const float* A, const float* B, int n, float x_update[6])
 /* ======================================================================== */
 /* Track::optimize.  src/track/optimize.cpp:10-99                            */
 /* ======================================================================== */
+/* The reference's literals (optimize.cpp:22-26, tracker.cpp:16-17).  orc_set_tracker_params overrides them for bench.py's
+ * "converging" side leg only (the product takes the same numbers through dvo_config); NULL / negative = back to the reference's. */
+static float g_step_default = 2.0f, g_step_l1 = 1.5f, g_step_l2 = 1.0f, g_min_residual = 5e-3f, g_min_update = 5e-4f;
+void orc_set_tracker_params(const float step3[3], float min_residual, float min_update)
+{
+    g_step_default = step3 ? step3[0] : 2.0f; g_step_l1 = step3 ? step3[1] : 1.5f; g_step_l2 = step3 ? step3[2] : 1.0f;
+    g_min_residual = min_residual < 0 ? 5e-3f : min_residual;
+    g_min_update = min_update < 0 ? 5e-4f : min_update;
+}
 static inline float level_step(int level)
 { /* optimize.cpp:22-26 */
-    if (level == 1) return 1.5f;
-    if (level == 2) return 1.0f;
-    return 2.0f;
+    if (level == 1) return g_step_l1;
+    if (level == 2) return g_step_l2;
+    return g_step_default;
 }
 
 /* per-pixel body shared by both variants: returns 1 and fills J[6], r, rw when the pixel contributes */
@@ -607,6 +659,17 @@ static int optimize_pixel(const float* obj_gray, const float* gradx, const float
     const float fx = K[0], fy = K[4];
     const float xx = X[0], yy = X[1], zz = X[2];
     const float fgx = fx * gx, fgy = fy * gy;
+    if (g_lit & ORC_LIT_ARITH) { /* optimize.cpp:67-77 as written */
+        const float x_ = xx, y_ = yy, z_ = zz;
+        const float xz_ = x_ / z_, yz_ = y_ / z_;
+        J[0] = fgx / z_;
+        J[1] = fgy / z_;
+        J[2] = -(fgx * x_ + fgy * y_) / z_ / z_;
+        J[3] = -fgx * xz_ * yz_ - fgy * (1.0f + yz_ * yz_);
+        J[4] = fgx * (1.0f + xz_ * xz_) + fgy * xz_ * yz_;
+        J[5] = (-fgx * yz_ + fgy * xz_);
+        goto residual;
+    }
     const float iz = 1.0f / zz; /* D8: the six divisions by z of optimize.cpp:70-74 share one reciprocal */
     const float xz = xx * iz, yz = yy * iz;
     J[0] = fgx * iz;
@@ -615,6 +678,7 @@ static int optimize_pixel(const float* obj_gray, const float* gradx, const float
     J[3] = -(((fgx * xz) * yz) + (fgy * fmaf(yz, yz, 1.0f)));
     J[4] = (fgx * fmaf(xz, xz, 1.0f)) + ((fgy * xz) * yz);
     J[5] = fmaf(fgy, xz, -(fgx * yz));
+residual:;
     const float r = I2 - I1; /* :79 */
     float sg = ref_sigma[i]; /* :83 std::clamp(sigma, 0.01, 0.5) */
     sg = sg < 0.01f ? 0.01f : (0.5f < sg ? 0.5f : sg);
@@ -808,7 +872,12 @@ void orc_track(const orc_frame* obj, const orc_frame* ref, int crop_enable, int 
             optimize_impl(obj->gray[level], ref->gray[level], gx, gy, ref->depth[level], ref->sigma[level],
                           w, h, ref->K[level], xi, level, crop_enable, variant, &o, NULL);
             float upd[6];
-            orc_se3_concatenate(xi, o.xi_update, upd); /* tracker.cpp:46 */
+            if (g_nudge && level == 0 && it == 0) {
+                for (int k = 0; k < (g_nudge < 0 ? -g_nudge : g_nudge); k++)
+                    o.xi_update[0] = nextafterf(o.xi_update[0], g_nudge > 0 ? INFINITY : -INFINITY);
+            }
+            if (g_lit & ORC_LIT_SE3) orc_se3_concatenate_f32lit(xi, o.xi_update, upd);
+            else orc_se3_concatenate(xi, o.xi_update, upd); /* tracker.cpp:46 */
             int ok = 1;
             for (int i = 0; i < 6; i++) if (isnan(upd[i])) ok = 0; /* tracker.cpp:47-51 testXi */
             if (ok) memcpy(xi, upd, sizeof xi);
@@ -823,7 +892,7 @@ void orc_track(const orc_frame* obj, const orc_frame* ref, int crop_enable, int 
                 memcpy(log->xi_after[level][it], xi, sizeof xi);
             }
             if (fixed_iters > 0) continue;
-            if (nrm < (double)5e-4f || o.residual < 5e-3f) break; /* tracker.cpp:68-69 (time stop disabled, D1) */
+            if (nrm < (double)g_min_update || o.residual < g_min_residual) break; /* tracker.cpp:68-69 (time stop disabled, D1) */
         }
         free(gx); free(gy);
     }
@@ -865,7 +934,7 @@ int orc_gaussian_update(float* depth, float* sigma, float d, float s, float rese
         *sigma = 0.5f;
         return 0;
     }
-    *depth = fmaf(v1, d, v2 * (*depth)) / v;
+    *depth = (g_lit & ORC_LIT_ARITH) ? (v2 * (*depth) + v1 * d) / v : fmaf(v1, d, v2 * (*depth)) / v;
     *sigma = sqrtf((v1 * v2) / v);
     return 1;
 }
@@ -877,7 +946,7 @@ int orc_gaussian_fuse(float* depth, float* sigma, float d, float s)
     const float gain = gauss_gain(d, diff);
     const float ms = *sigma < s ? s : *sigma;
     if (diff > gain * ms) return 0;
-    *depth = fmaf(v1, d, v2 * (*depth)) / v;
+    *depth = (g_lit & ORC_LIT_ARITH) ? (v2 * (*depth) + v1 * d) / v : fmaf(v1, d, v2 * (*depth)) / v;
     *sigma = sqrtf((v1 * v2) / v);
     return 1;
 }
@@ -916,7 +985,7 @@ void orc_propagate(const float* ref_depth, const float* ref_sigma, const float* 
             const float d1 = d0 + tz;
             const float q = d1 / d0;
             const float q4 = q * (q * (q * q)); /* math::pow(q,4): util.hpp:19-27 */
-            s = sqrtf(fmaf(q4, s * s, pv));
+            s = (g_lit & ORC_LIT_ARITH) ? sqrtf(q4 * (s * s) + pv) : sqrtf(fmaf(q4, s * s, pv));
             const int o = qy * w + qx;
             depth[o] = d1 < 0.0f ? 0.0f : d1; /* std::max(d1, 0) */
             sigma[o] = s;
@@ -1015,7 +1084,7 @@ void orc_implement_update(const float* obj_gray, const float* born_gray, const f
         my = my < 0 ? 0 : (my > h - 1 ? h - 1 : my);
         const float gx = born_gx[my * w + mx], gy = born_gy[my * w + mx];
         if (is_invalid(gx) || is_invalid(gy)) { *new_sigma = -1.0f; return; }
-        const float gl = fabsf(fmaf(gy, ly, gx * lx));
+        const float gl = (g_lit & ORC_LIT_ARITH) ? fabsf(gx * lx + gy * ly) : fabsf(fmaf(gy, ly, gx * lx));
         const float gl2 = gl * gl;
         const float gp2 = gl / l;
         const float epi = 0.25f / (gl2 < ORC_EPSILON ? ORC_EPSILON : gl2);

@@ -59,6 +59,16 @@ extern "C" {
 void orc_set_threads(int n);
 int  orc_get_threads(void);
 
+/* Arithmetic mode -- instrumentation for the D8 / D2 sensitivity measurements only (tests/test_oracle_literal.py, bench.py's
+ * accuracy.oracle_self_sensitivity).  0 = canonical (what every parity test compares the GPU against). */
+#define ORC_LIT_ARITH 1  /* per-pixel expressions exactly as the source writes them: true divisions, no fmaf, no shared reciprocal */
+#define ORC_LIT_SE3   2  /* per-pixel pose and pose composition from the float-literal se3.cpp restatement (orc_se3_*_f32lit) */
+void orc_set_literal(int mask);
+int  orc_get_literal(void);
+/* step[3] = {default, level 1, level 2} (optimize.cpp:22-26), stop thresholds (tracker.cpp:16-17); NULL / negative = the reference's */
+void orc_set_tracker_params(const float step3[3], float min_residual, float min_update);
+void orc_set_nudge_ulps(int n);   /* orc_track: first xi_update component of level 0 / iteration 0 moved by n ulps (0 = off) */
+
 /* ---- math/se3.cpp ---------------------------------------------------- */
 void orc_se3_exp(const float xi[6], float T[16]);               /* se3.cpp:70-98  (double inside, D2) */
 void orc_se3_log(const float T[16], float xi[6]);               /* se3.cpp:101-124 */

@@ -89,6 +89,42 @@ def set_threads(n):
     lib().orc_set_threads(int(n))
 
 
+LIT_ARITH, LIT_SE3 = 1, 2
+
+
+def set_literal(mask):
+    """Arithmetic mode of the oracle (dvo_oracle.h): 0 = canonical (D8 order, SE(3) in double); LIT_ARITH = per-pixel expressions as
+    the reference source writes them; LIT_SE3 = float-literal se3.cpp.  Sensitivity measurements only."""
+    lib().orc_set_literal(int(mask))
+
+
+def set_tracker_params(step3=None, min_residual=-1.0, min_update=-1.0):
+    """override the reference's step / stop literals (bench.py's converging side leg only); no arguments = back to the reference's"""
+    if step3 is None:
+        lib().orc_set_tracker_params(None, C.c_float(min_residual), C.c_float(min_update))
+    else:
+        st = f32(step3)
+        lib().orc_set_tracker_params(fp(st), C.c_float(min_residual), C.c_float(min_update))
+
+
+def set_nudge_ulps(n):
+    """orc_track moves the first component of its first xi_update by n ulps (sensitivity probe; 0 = off)."""
+    lib().orc_set_nudge_ulps(int(n))
+
+
+class literal:
+    """with orc.literal(orc.LIT_ARITH): ... -- never while other threads run oracle calls."""
+
+    def __init__(self, mask=LIT_ARITH, nudge=0):
+        self.mask, self.nudge = mask, nudge
+
+    def __enter__(self):
+        set_literal(self.mask); set_nudge_ulps(self.nudge)
+
+    def __exit__(self, *a):
+        set_literal(0); set_nudge_ulps(0)
+
+
 def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

@@ -167,3 +167,55 @@ def test_mono_batch_rejects_sensor_depth_calls_and_vice_versa():
     bt.close()
     with pytest.raises(dvo.DvoError):
         dvo.MonoBatch(0, K640, 640, 480)
+
+
+def test_mono_batch_failed_first_frame_leaves_the_batch_not_started():
+    """A call that fails (here: a channel count the raw path rejects, a null pointer) must not advance Frame::latest_id: the batch stays
+    in the not-started state, and the next good frame IS frame 0 (first keyframe, identity pose) -- frame ids never shift."""
+    import torch
+    g = frames(6, seed=7)[0]
+    dev = torch.device("cuda", 0)
+    mb = dvo.MonoBatch(2, K640, 640, 480, cfg=dvo.default_config(rng_seed=3))
+    L = dvo.lib()
+    g8 = torch.zeros((2, 480, 640, 2), dtype=torch.uint8, device=dev)
+    assert L.dvo_batch_odometrize_raw_device(mb._p, dvo.C.c_void_p(g8.data_ptr()), 2) != 0      # 2 channels: rejected
+    assert L.dvo_batch_odometrize_device(mb._p, None) != 0
+    assert L.dvo_batch_world_poses(mb._p, None, None, None) == dvo.DVO_ERR_NOT_READY            # still not started
+    st = dvo.MonoStats()
+    assert L.dvo_batch_mono_stats(mb._p, 0, dvo.C.byref(st)) == dvo.DVO_ERR_NOT_READY
+    gb = torch.from_numpy(np.stack([g[0], g[1]])).to(dev)
+    mb.odometrize_device(gb.data_ptr())
+    xi, T, key = mb.world_poses()
+    assert key.all() and np.array_equal(T[0], np.eye(4, dtype=np.float32))
+    assert mb.stats(0)["frames"] == 1 and mb.stats(1)["keyframes_created"] == 1
+    # a failed call in the middle does not consume a frame id either
+    assert L.dvo_batch_odometrize_device(mb._p, None) != 0
+    gb2 = torch.from_numpy(np.stack([g[1], g[2]])).to(dev)
+    mb.odometrize_device(gb2.data_ptr())
+    assert mb.stats(0)["frames"] == 2
+    mb.close()
+
+
+def test_mono_batch_ring_clamp_is_counted():
+    """ring of 2 keyframes, more than 2 created: pixels older than the ring are searched against the oldest retained keyframe
+    (the one deviation from the reference's unbounded FrameHistory) -- and every such pixel is counted (dvo_mono_stats)."""
+    import torch
+    B, n_frames = 3, 10
+    rng = np.random.RandomState(5)
+    g, d, s, _ = frames(6, seed=7)
+    d0 = orc.cull_image(d[0], 2)
+    init_d = (d0 + rng.normal(0, 0.1, d0.shape)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    counts = {}
+    for ring in (2, 16):
+        mb = dvo.MonoBatch(B, K640, 640, 480, ring_keyframes=ring, cfg=dvo.default_config(rng_seed=3))
+        mb.setInitialDepth(init_d, np.full_like(init_d, 0.5))
+        for k in range(n_frames):
+            gb = torch.from_numpy(np.stack([g[(b + 2 * k + (k // 3)) % 6] for b in range(B)])).to(dev)
+            mb.odometrize_device(gb.data_ptr())
+        counts[ring] = [mb.stats(b) for b in range(B)]
+        mb.close()
+    assert max(s["keyframes_created"] for s in counts[2]) > 2
+    assert sum(s["clamped_pixels"] for s in counts[2]) > 0          # the ring of 2 overflowed and said so
+    assert sum(s["clamped_pixels"] for s in counts[16]) == 0        # a ring that holds every keyframe never clamps
+    assert counts[2][0]["ring_keyframes"] == 2

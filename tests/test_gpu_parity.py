@@ -7,7 +7,7 @@ import pytest
 
 import dvo_amd as dvo
 import orc
-from util import K640, TOL_H_REL, TOL_POSE, TOL_UPD_ABS, TOL_UPD_REL, frames
+from util import K640, TOL_BACKWARD, TOL_H_REL, TOL_POSE, TOL_UPD_ABS, TOL_UPD_REL, assert_composed, backward_error, frames
 
 pytestmark = pytest.mark.gpu
 INV = np.float32(-2.0)
@@ -185,7 +185,9 @@ def test_track_over_relaxed_gain_per_iteration_parity():
             r = dvo.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l)
             assert r["n_valid"] == lo["n_valid"][l][it]
             np.testing.assert_allclose(r["residual"], lo["residual"][l][it], rtol=1e-4)
-            np.testing.assert_allclose(r["xi_next"], lo["xi_after"][l][it], rtol=0, atol=2e-4 * max(1.0, np.abs(xi).max() * 50))
+            o = orc.optimize(obj.gray(l), ref.gray(l), ref.depth(l), ref.sigma(l), ref.K(l), xi, l)
+            assert backward_error(o["H"], o["g"], r["xi_update"]) <= TOL_BACKWARD, (l, it)
+            assert_composed(xi, r["xi_update"], r["xi_next"], tag=(l, it))
             xi = lo["xi_after"][l][it]  # follow the oracle's trajectory
 
 
