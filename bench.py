@@ -446,7 +446,7 @@ def run_depth(a, env, role="headline", data=None):
                     out["roofline"]["valu_instructions_per_pixel"] = {"value": valu / waves / 4.0,  # 4 pixels per lane (PPT)
                                                                       "source": "profiles/" + os.path.basename(fn)}
                     break
-            if a.fixed_iters == 0 or a.workload == "syn1080":
+            if head and (a.fixed_iters == 0 or a.workload == "syn1080"):
                 for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), key=_natural, reverse=True):
                     with open(fn) as fh:
                         tr = json.load(fh)
@@ -458,6 +458,9 @@ def run_depth(a, env, role="headline", data=None):
     # ---- parity sample (oracle = checker): a small batch over the first sequences, logs read back after every step ----------
     parity_fail = None
     gpu_iters = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and NS > 0 and tracker_over:   # the oracle takes the same non-reference constants
+        env.orc.set_tracker_params([tracker_over.get("step_default", 2.0), tracker_over.get("step_level1", 1.5), tracker_over.get("step_level2", 1.0)],
+                                   tracker_over.get("min_residual", -1.0), -1.0)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and NS > 0:
         orc = env.orc
         from concurrent.futures import ThreadPoolExecutor
@@ -554,9 +557,6 @@ def run_depth(a, env, role="headline", data=None):
         from concurrent.futures import ThreadPoolExecutor
         ncore = env.ncore
         gh, dh, sh = host_frames(slice(None), slice(0, NS))  # [F][NS][H][W]
-        if tracker_over:
-            orc.set_tracker_params([tracker_over.get("step_default", 2.0), tracker_over.get("step_level1", 1.5), tracker_over.get("step_level2", 1.0)],
-                                   tracker_over.get("min_residual", -1.0), -1.0)
 
         def seq_job(b):
             res = []
@@ -655,8 +655,8 @@ def run_depth(a, env, role="headline", data=None):
             if "secondary" in out:
                 out["secondary"]["single_stream_vs_cpu_baseline"] = {"x_all_cores": out["secondary"]["single_stream_odometrizeUsingDepth_fps"] / all_fps,
                                                                      "x_one_core": out["secondary"]["single_stream_odometrizeUsingDepth_fps"] / one_fps}
-        if tracker_over:
-            orc.set_tracker_params()
+    if tracker_over and env._orc is not None:
+        env.orc.set_tracker_params()
     return out, data, parity_fail
 
 
