@@ -127,7 +127,7 @@ int dvo_vo_odometrize_depth(dvo_vo* vo, const float* gray, const float* depth, c
 int dvo_vo_odometrize_depth_raw(dvo_vo* vo, const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
 {
     if (!vo) return DVO_ERR_BAD_ARGUMENT;
-    return vo->impl.odometrize_depth_raw(rgb, channels, depth16, depth_scale, T_rel);
+    return vo->impl.odometrize_depth_raw(rgb, channels, depth16, depth_scale > 0.0f ? depth_scale : 1.0f / 5000.0f, T_rel);   // (0 = the TUM scale, as the batch entries)
 }
 
 int dvo_vo_keyframe_count(const dvo_vo* vo) { return vo ? (int)vo->impl.hist.size() : 0; }
@@ -180,6 +180,7 @@ int dvo_vo_last_valid_updates(const dvo_vo* vo) { return vo ? vo->impl.last_vali
 int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log)
 {
     if (!vo || !log) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(const_cast<dvo_vo*>(vo)->impl.fetch_log());   // (read back on demand: the record is not part of the per-frame hand-over)
     *log = vo->impl.last_log;
     return DVO_OK;
 }

@@ -276,6 +276,7 @@ Tracker::~Tracker()
 {
     if (h_state) (void)hipHostFree(h_state);
     if (h_progress) (void)hipHostFree(h_progress);
+    if (h_result) (void)hipHostFree(h_result);
     for (auto st : sub_streams) (void)hipStreamDestroy(st);
     for (auto e : ev_join) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -580,8 +581,41 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         DVO_HIP(hipEventRecord(ev_join[k - 1], sub_streams[k - 1]));
         DVO_HIP(hipStreamWaitEvent(s, ev_join[k - 1], 0));
     }
-    launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s);
+    if (h_result) result_tag++;
+    launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s, d_result, result_tag);
     DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int Tracker::enable_host_result()
+{
+    if (h_result) return DVO_OK;
+    DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_result), 32 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_result, 0, 32 * sizeof(float));
+    DVO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_result), h_result, 0));
+    return DVO_OK;
+}
+
+int Tracker::wait_host_result(hipStream_t s, float xi[6], float T[16])
+{
+    if (!h_result) { set_error("host result not enabled"); return DVO_ERR_NOT_READY; }
+    volatile int* tag = reinterpret_cast<volatile int*>(h_result + 22);
+    long spins = 0;
+    while (*tag != result_tag) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {   // every ~1 M polls: has the stream finished (or failed) without the tag appearing?
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {
+                if (*tag == result_tag) break;
+                set_error("track(): the stream drained but the result tag never arrived");
+                return DVO_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { set_error(hipGetErrorString(q)); return DVO_ERR_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < 6; i++) xi[i] = h_result[i];
+    for (int i = 0; i < 16; i++) T[i] = h_result[6 + i];
     return DVO_OK;
 }
 
@@ -607,6 +641,16 @@ int Keyframe::alloc(const Geometry& g, const dvo_config& cfg)
 }
 
 // ------------------------------------------------------------------------------------------------ VisualOdometry
+int VisualOdometry::fetch_log()
+{
+    if (!log_src) return DVO_OK;
+    DVO_TRY(select_device(device));
+    DVO_HIP(hipMemcpyAsync(&last_log, log_src->log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));
+    log_src = nullptr;
+    return DVO_OK;
+}
+
 VisualOdometry::~VisualOdometry()
 {
     if (h_pin) (void)hipHostFree(h_pin);
@@ -793,6 +837,7 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     DVO_HIP(hipStreamSynchronize(stream));
     memcpy(&h_meta, h_pin, sizeof h_meta);
     memcpy(&last_log, reinterpret_cast<char*>(h_pin) + sizeof(MonoSeq), sizeof last_log);
+    log_src = nullptr;
     memcpy(frame.rel_xi, h_meta.rel_xi, sizeof frame.rel_xi);
     memcpy(frame.xi, h_meta.frame_xi, sizeof frame.xi);
     frame.ref_id = ref.id;
@@ -862,12 +907,13 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* r
         se3_exp_f(z, T_rel);
         return DVO_OK;
     }
+    DVO_TRY(trkD.enable_host_result());
     DVO_TRY(trkD.track(frame.fs, depth_ref->fs, stream));
+    // The pose comes back through mapped host memory (k_export_poses' last store), not through a copy + stream synchronisation; the
+    // caller's input buffers were consumed by copies that are stream-ordered before the kernels whose result this waits for.
     float rel[6];
-    DVO_HIP(hipMemcpyAsync(rel, trkD.xi_out.p, sizeof rel, hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipMemcpyAsync(T_rel, trkD.T_out.p, 16 * sizeof(float), hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipMemcpyAsync(&last_log, trkD.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipStreamSynchronize(stream));
+    DVO_TRY(trkD.wait_host_result(stream, rel, T_rel));
+    log_src = &trkD;   // the per-iteration log stays on the device until dvo_vo_last_track_log asks for it
     memcpy(frame.rel_xi, rel, sizeof rel);
     frame.ref_id = depth_ref->id;
     se3_concatenate_f(depth_ref->xi, rel, frame.xi);

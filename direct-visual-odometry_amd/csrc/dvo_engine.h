@@ -131,6 +131,13 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     SeqState* h_state = nullptr;  // pinned host mirror of `state` for the small-batch convergence poll
     int tile_margin = 0;  // > 0: k_track_gn_tile (LDS-staged reference patch); 0: k_track_gn (global gathers)
     void launch_gn(const GnArgs& a, int level, int count, hipStream_t s, int grid_seqs = 0) const;  // `a` views `count` sequences
+    // Result hand-over for a handle that returns one pose per call (dvo_vo): k_export_poses also writes xi, T and a tag into
+    // fine-grained mapped host memory, and wait_host_result() polls the tag -- no device-to-host copy, no stream synchronisation.
+    float* h_result = nullptr;   // host view: [0..5] xi, [6..21] T, [22] tag (int)
+    float* d_result = nullptr;   // device view of the same memory
+    int result_tag = 0;
+    int enable_host_result();
+    int wait_host_result(hipStream_t s, float xi[6], float T[16]);   // of the last track() call
     // profiling (cfg.profile)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -178,6 +185,8 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int last_id = -1, last_valid_updates = 0;
     float last_xi[6] = {0}, last_rel[6] = {0};
     dvo_track_log last_log;
+    Tracker* log_src = nullptr;                        // the tracker whose device log is newer than last_log (read back on demand only)
+    int fetch_log();                                   // dvo_vo_last_track_log: the 15 KB per-iteration record is copied when asked for
     ~VisualOdometry();
     int init(const float K9[9], int width, int height, const dvo_config* c);
     int odometrize(const float* gray, float T_world[16], int* is_key, const uint8_t* raw = nullptr, int raw_channels = 0);

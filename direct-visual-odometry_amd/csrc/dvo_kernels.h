@@ -281,7 +281,7 @@ inline bool gn_fused_available(int ppt, int group) { return (ppt == 1 && group =
 void launch_track_level(const GnArgs& ga, const SolveArgs& sa, int n_seq, hipStream_t s);
 void launch_track_begin(SeqState* state, dvo_track_log* log, int n_seq, int levels, hipStream_t s);
 void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_t s);
-void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s);
+void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s, float* host_result = nullptr, int host_tag = 0);
 void launch_se3(int op, const float* a, const float* b, float* out, hipStream_t s);
 void launch_propagate(const float* ref_depth, const float* ref_sigma, const float* ref_age, int w, int h, const Intr& k,
                       const Pose& pose, float tz, int* owner, float* depth, float* sigma, float* age, hipStream_t s);

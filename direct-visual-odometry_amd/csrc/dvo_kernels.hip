@@ -834,9 +834,38 @@ __device__ __forceinline__ double sum_partial_rows(const float* p, const int nbl
     return (sg[0] + sg[1]) + (sg[2] + sg[3]);
 }
 
+// One row class g of sum_partial_rows() -- the rows b = g (mod 4) in increasing b, i.e. exactly the additions that function performs
+// for sg[g], in its order -- with EVERY load of the class issued before the first addition (up to DVO_WIDE_BATCHES x 8 rows per lane:
+// nblk <= 32 * DVO_WIDE_BATCHES).  One sequence gives a 32-lane team per class instead of one team for all four: a dvo_vo handle's
+// finest level (300 partial rows) took ten dependent memory round trips here, ~15 us of its 20 us solve kernel; now one.
+// (s0 + s1) + (s2 + s3) of the four results are the bits sum_partial_rows() returns.
+#define DVO_WIDE_BATCHES 10
+__device__ __forceinline__ double sum_partial_class(const float* p, const int nblk, const int blk_first, const int blk_count, const int g)
+{
+    const int live0 = blk_count < 0 ? 0 : blk_first, live1 = blk_count < 0 ? nblk : blk_first + blk_count;
+    float v[DVO_WIDE_BATCHES][8];
+#pragma unroll
+    for (int bi = 0; bi < DVO_WIDE_BATCHES; bi++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = 32 * bi + g + DVO_SOLVE_GROUPS * j;
+            const bool live = (32 * bi < nblk) & (b >= live0) & (b < live1);
+            const float x = p[(size_t)(live ? b : 0) * 32];
+            v[bi][j] = live ? x : 0.0f;
+        }
+    double sg = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < DVO_WIDE_BATCHES; bi++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (32 * bi < nblk && 32 * bi + g < nblk) sg += (double)v[bi][j];   // (the same zeros in the same slots as sum_partial_rows)
+    return sg;
+}
+
 __global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
 {
     __shared__ double tot[DVO_SOLVE_SEQ][32];
+    __shared__ double part[2][DVO_SOLVE_GROUPS][32];
     const int n_in = a.list_in ? a.list_in[0] : a.n_seq;  // sequences this launch handles
     // progress word in mapped host memory (adaptive schedule, Tracker::track): "iteration reached, n sequences were active".
     // Kept out of k_track_gn on purpose: that kernel sits exactly at its 72-VGPR budget and one more live value makes it spill.
@@ -865,7 +894,18 @@ __global__ void __launch_bounds__(32 * DVO_SOLVE_SEQ) k_gn_solve(SolveArgs a)
     // stage one: second reduction of the workgroup partials, fixed order (bit-reproducible; k_track_level mirrors it)
     const int c = threadIdx.x & 31, team = threadIdx.x >> 5;
     const int t_slot = (int)blockIdx.x * DVO_SOLVE_SEQ + team;
-    if (t_slot < n_in && c < 29) {
+    if (n_in <= 2 && a.nblk <= 32 * DVO_WIDE_BATCHES) {   // (workgroup-uniform) one or two sequences: a team per row class, one round trip
+        const int ws = team >> 2, wg = team & 3;
+        if (ws < n_in && c < 29) {
+            const int t_seq = a.list_in ? a.list_in[4 + ws] : ws;
+            part[ws][wg][c] = sum_partial_class(a.partials + (size_t)t_seq * a.nblk * 32 + c, a.nblk, a.blk_first, a.blk_count, wg);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int ts = threadIdx.x >> 5;
+            tot[ts][c] = (ts < n_in && c < 29) ? (part[ts][0][c] + part[ts][1][c]) + (part[ts][2][c] + part[ts][3][c]) : 0.0;
+        }
+    } else if (t_slot < n_in && c < 29) {
         const int t_seq = a.list_in ? a.list_in[4 + t_slot] : t_slot;
         tot[team][c] = sum_partial_rows(a.partials + (size_t)t_seq * a.nblk * 32 + c, a.nblk, a.blk_first, a.blk_count);
     } else if (c >= 29) {
@@ -966,6 +1006,7 @@ __global__ void __launch_bounds__(256) k_track_gn_fused(GnArgs a, SolveArgs sa, 
 {
     __shared__ GnTileLds<PPT> lds;
     __shared__ double tot[32];
+    __shared__ double part[DVO_SOLVE_GROUPS][32];
     __shared__ int last_s;
     const int tile_id = (int)blockIdx.x;                       // grid = n_seq * blk_count exactly
     const int seq = tile_id / a.blk_count, blk = a.blk_first + (tile_id - seq * a.blk_count);
@@ -1000,7 +1041,13 @@ __global__ void __launch_bounds__(256) k_track_gn_fused(GnArgs a, SolveArgs sa, 
     }
     __syncthreads();
     if (!last_s) return;
-    if (threadIdx.x < 32) {
+    if (a.nblk <= 32 * DVO_WIDE_BATCHES) {                        // a team per row class: every partial row requested at once
+        const int c = threadIdx.x & 31, wg = (int)(threadIdx.x >> 5);
+        if (wg < DVO_SOLVE_GROUPS && c < 29)
+            part[wg][c] = sum_partial_class(a.partials + (size_t)seq * a.nblk * 32 + c, a.nblk, sa.blk_first, sa.blk_count, wg);
+        __syncthreads();
+        if (threadIdx.x < 32) tot[c] = c < 29 ? (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]) : 0.0;
+    } else if (threadIdx.x < 32) {
         const int c = threadIdx.x;
         tot[c] = c < 29 ? sum_partial_rows(a.partials + (size_t)seq * a.nblk * 32 + c, a.nblk, sa.blk_first, sa.blk_count) : 0.0;
     }
@@ -1133,7 +1180,10 @@ __global__ void k_set_pose(SeqState* state, const float* xi, int n_seq)
 }
 
 // k_export_poses: relative twist + exp(xi) 4x4 (system.hpp:92) per sequence
-__global__ void k_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq)
+// host_result (optional, fine-grained mapped HOST memory, one sequence): the same 22 floats, then a sequence word written with a
+// system-scope release store -- the caller's thread polls it instead of queueing a device-to-host copy and waiting for the stream
+// (a dvo_vo handle returns one pose per call: three small copies + a stream synchronisation were ~55 us of every frame).
+__global__ void k_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, float* host_result, int host_tag)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seq) return;
@@ -1141,6 +1191,11 @@ __global__ void k_export_poses(const SeqState* state, float* xi_out, float* T_ou
     for (int i = 0; i < 6; i++) { x[i] = state[s].xi[i]; xi_out[s * 6 + i] = x[i]; }
     se3_exp_f(x, T);
     for (int i = 0; i < 16; i++) T_out[s * 16 + i] = T[i];
+    if (host_result && s == 0) {
+        for (int i = 0; i < 6; i++) host_result[i] = x[i];
+        for (int i = 0; i < 16; i++) host_result[6 + i] = T[i];
+        __hip_atomic_store(reinterpret_cast<int*>(host_result + 22), host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // k_se3: device evaluation of the double-precision pose algebra (parity op): op 0 exp, 1 log, 2 concatenate
@@ -1471,9 +1526,9 @@ void launch_set_pose(SeqState* state, const float* xi_dev, int n_seq, hipStream_
     hipLaunchKernelGGL(k_set_pose, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, state, xi_dev, n_seq);
 }
 
-void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s)
+void launch_export_poses(const SeqState* state, float* xi_out, float* T_out, int n_seq, hipStream_t s, float* host_result, int host_tag)
 {
-    hipLaunchKernelGGL(k_export_poses, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, state, xi_out, T_out, n_seq);
+    hipLaunchKernelGGL(k_export_poses, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, state, xi_out, T_out, n_seq, host_result, host_tag);
 }
 
 void launch_se3(int op, const float* a, const float* b, float* out, hipStream_t s)

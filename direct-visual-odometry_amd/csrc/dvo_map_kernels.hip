@@ -342,6 +342,7 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
     const float og = a.obj_gray[base + qy * w + qx];
     const float dirx = (ex - sx) / length, diry = (ey - sy) / length;
     float ptx = sx, pty = sy, bestx = sx, besty = sy, min_ssd = 6.0f;
+    float s_c = 0.0f, s_pc = 0.0f, pcx = 0.0f, pcy = 0.0f;   // sample reuse between steps (see the loop)
     int count = 0;
     // The loop test of implement.cpp:113 is sqrt(dx^2 + dy^2) < length in double.  With L2 = length^2 (exact in double), that is
     // decided without the square root whenever dx^2 + dy^2 is not within a relative 1e-12 of L2 (sqrt is monotonic and correctly
@@ -367,32 +368,47 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
         float ssd = 0.0f;
         ptx += dirx;
         pty += diry;
-        // The three samples of a step are independent of each other: all 12 taps are requested before any is used (three gather
-        // round trips in flight instead of one after the other).  The reference's early exit -- the first INVALID sample sets
-        // ssd = 6 and leaves (implement.cpp:128-131) -- is then applied to the loaded values: same result.
+        // A step samples at pt - dir, pt and pt + dir (implement.cpp:124-126: pt + (i - N/2) * dir, i = 0, 1, 2).  pt + dir is, bit for
+        // bit, the NEXT step's pt (the same float addition), so that sample is computed once and is the next step's centre; and
+        // pt - dir equals the PREVIOUS step's pt except where the addition rounded across a binade (checked per step and lane, in
+        // both coordinates): then the previous centre sample is this step's first.  Same coordinates -> same taps, fractions and
+        // blend -> the same sample values as three evaluations per step, for ~1.3 evaluations (one new sample, plus the first one
+        // again for the whole wave when any lane's round trip failed).  The first step of a pixel evaluates all three.
+        // The reference's early exit -- the first INVALID sample sets ssd = 6 and leaves (implement.cpp:128-131) -- is applied to
+        // the values: same result.
         float sgv[3];
+        const float nx = ptx + dirx * -1.0f, ny = pty + diry * -1.0f;   // (the literal expressions of the three targets)
+        const float cx = ptx + dirx * 0.0f, cy = pty + diry * 0.0f;
+        const float fx = ptx + dirx * 1.0f, fy = pty + diry * 1.0f;
+        const bool first = count == 0;                                     // wave-uniform: the lanes of a wave enter the loop together
+        // (cx, cy) == the previous step's (fx, fy) holds by construction from the second step on (cx = pt + 0*dir = pt for finite dir;
+        //  for a non-finite dir every sample of every step is INVALID either way)
+        const bool need_n = first | !((nx == pcx) & (ny == pcy));
+        const bool any_n = __ballot(need_n) != 0ull;
         // Interior fast path: pt in [2, w-3) x [2, h-3) and |dir| <= 1 (+ an ulp) put all three samples' 2 x 2 footprints inside the
         // image, where Convert::getSubpixelFromDense (convert.cpp:77-105) has no clamp, no range test and no INVALID exit: the same
         // truncation, fractions and blend4() without ~20 instructions of bounds logic per sample.  Wave-uniform choice.
         const bool inner = (ptx >= 2.0f) & (ptx < (float)(w - 3)) & (pty >= 2.0f) & (pty < (float)(h - 3));
+        float s_n = s_pc, s_f;
         if (__ballot(!inner) == 0ull) {
-#pragma unroll
-            for (int jj = 0; jj < 3; jj++) {
-                const float kf = (float)(jj - 1);
-                const float px = ptx + dirx * kf, py = pty + diry * kf;
+            auto fast = [&](float px, float py) {
                 const int x0 = (int)px, y0 = (int)py;
                 // (global address space stated: born_gray may come from a pointer table, which makes it a flat pointer -- and flat loads
                 //  also count against lgkmcnt and take the aperture check)
                 const __attribute__((address_space(1))) float* q = (const __attribute__((address_space(1))) float*)born_gray + (y0 * w + x0);
-                sgv[jj] = blend4(q[0], q[1], q[w], q[w + 1], px - (float)x0, py - (float)y0);
-            }
+                return blend4(q[0], q[1], q[w], q[w + 1], px - (float)x0, py - (float)y0);
+            };
+            s_f = fast(fx, fy);
+            if (first) s_c = fast(cx, cy);
+            if (any_n) { const float t = fast(nx, ny); s_n = need_n ? t : s_pc; }
         } else {
-#pragma unroll
-            for (int jj = 0; jj < 3; jj++) {
-                const float kf = (float)(jj - 1);
-                sgv[jj] = get_subpixel_dense(bg, ptx + dirx * kf, pty + diry * kf);
-            }
+            s_f = get_subpixel_dense(bg, fx, fy);
+            if (first) s_c = get_subpixel_dense(bg, cx, cy);
+            if (any_n) { const float t = get_subpixel_dense(bg, nx, ny); s_n = need_n ? t : s_pc; }
         }
+        sgv[0] = s_n; sgv[1] = s_c; sgv[2] = s_f;
+        s_pc = s_c; pcx = cx; pcy = cy;      // this step's centre: the next step's first sample where the round trip holds
+        s_c = s_f;                           // this step's far sample: the next step's centre
         bool any_invalid = false;
 #pragma unroll
         for (int jj = 0; jj < 3; jj++) {
