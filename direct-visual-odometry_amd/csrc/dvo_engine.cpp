@@ -330,7 +330,10 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
             const GnTiling t4 = gn_tiling(g.w[l], g.h[l], 4, crop_l);
             fused[l] = fuse_max > 0 && !t4.t2d && t4.count <= fuse_max;  // (k_track_level: raster tiles)
             if (fused[l]) p = 4;
-            while (!fused[l] && auto_p && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l) < 1024) p >>= 1;
+            // (one sequence on the one-launch-per-call schedule keeps 4 pixels per thread: k_track_persist's workgroups wait for each
+            //  other, and 75 of them hand over faster than 300 -- 406 against 451 us per 640x480 frame, profiles/r03_single_ab.txt)
+            const bool single_p4 = prefer_persist && n_seq == 1 && cfg.track_single_launch == 0 && !cfg.profile;
+            while (!fused[l] && auto_p && !single_p4 && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l) < 1024) p >>= 1;
             nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l);
             tiles_x[l] = tiles_y[l] = 0;
         }
@@ -379,6 +382,25 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         const GnTiling tl = gn_tiling(g.w[l], g.h[l], ppt[l], level_params(l).crop);
         single_launch[l] = cfg.track_single_launch >= 0 && n_seq <= 8 && tile_margin == 0 && !fused[l] && !cfg.profile && n_sub == 1 &&
                            gn_fused_available(ppt[l], group[l]) && tl.live_count > 0 && (long long)n_seq * tl.live_count <= 64;
+    }
+    // k_track_persist (one launch per track() call): one sequence, the global-gather kernel, one (ppt, group) pair on every level,
+    // every level within the wide reduction's row limit, no profiling; track_single_launch: < 0 = launch pairs only, 1 = one launch per
+    // iteration at most (k_track_gn_fused), 0 (default) = one launch per call where the result goes through enable_host_result()
+    persist_ok = prefer_persist && n_seq == 1 && tile_margin == 0 && !cfg.profile && cfg.track_single_launch == 0 && n_sub == 1 && track_persist_available(ppt[0], group[0]);
+    int max_tiles = 0;
+    for (int l = 0; l < g.levels && persist_ok; l++) {
+        const GnTiling tl = gn_tiling(g.w[l], g.h[l], ppt[l], level_params(l).crop);
+        if (ppt[l] != ppt[0] || group[l] != group[0] || fused[l] || nblk[l] > 320 || tl.live_count <= 0) persist_ok = false;
+        if (tl.live_count > max_tiles) max_tiles = tl.live_count;
+    }
+    if (persist_ok) {
+        int cap = 0;
+        if (track_persist_max_grid(ppt[0], group[0], &cap) != DVO_OK || cap < 1) persist_ok = false;
+        else {
+            persist_grid = 1 + (max_tiles < cap - 1 ? max_tiles : cap - 1);   // the solver + one worker per tile of the largest level, all resident at once (they wait for each other)
+            DVO_TRY(persist_ctl.alloc((16 + (size_t)persist_grid) * sizeof(int)));   // control line (64 B) + one arrival slot per workgroup
+            DVO_HIP(hipMemset(persist_ctl.p, 0, persist_ctl.bytes));
+        }
     }
     DVO_TRY(ticket.alloc(sizeof(int) * (size_t)n_seq));
     DVO_HIP(hipMemset(ticket.p, 0, ticket.bytes));
@@ -432,6 +454,37 @@ void Tracker::launch_gn(const GnArgs& a, int level, int count, hipStream_t s, in
 
 int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
 {
+    last_obj = &obj; last_ref = &ref;
+    persist_used = false;
+    if (persist_ok && !persist_failed && h_result) {   // the whole call in one launch (k_track_persist)
+        PersistArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.levels = g.levels;
+        for (int l = 0; l < g.levels; l++) {
+            const GnArgs ga = gn_args(obj, ref, l, nullptr, 0);
+            const GnTiling tl = gn_tiling(ga.w, ga.h, ppt[l], ga.prm.crop);
+            PersistLevel& L = pa.lv[l];
+            L.obj_gray = ga.obj_gray; L.ref_gray = ga.ref_gray; L.ref_depth = ga.ref_depth; L.ref_wgt = ga.ref_wgt; L.wgt_const = ga.wgt_const;
+            L.inv_w = ga.inv_w; L.w = ga.w; L.h = ga.h; L.nblk = ga.nblk; L.q256 = ga.q256; L.r256 = ga.r256; L.k = ga.k; L.prm = ga.prm;
+            L.blk_first = tl.live_first; L.blk_count = tl.live_count; L.t_shift = tl.shift; L.x_org = tl.x_org; L.y_org = tl.y_org;
+            L.tiles_x = tl.t2d ? tl.tiles_x : 0; L.t2d = tl.t2d; L.level_pixels = (int)tl.live_pixels;
+        }
+        pa.state = state.as<SeqState>(); pa.partials = partials.as<float>(); pa.log = log.as<dvo_track_log>();
+        pa.ctl = persist_ctl.as<int>();
+        pa.max_iterations = cfg.max_iterations; pa.fixed_iterations = cfg.fixed_iterations;
+        pa.min_update = cfg.min_update; pa.min_residual = cfg.min_residual;
+        pa.xi_out = xi_out.as<float>(); pa.T_out = T_out.as<float>(); pa.host_result = d_result;
+        result_tag = (result_tag + 1) & 0x1fffff;
+        if (result_tag == 0) result_tag = 1;
+        pa.host_tag = result_tag;
+        pa.spin_limit = 1 << 18;   // ~0.2 s of polling: far beyond any iteration, short enough that a wedged launch ends
+        if (const char* e = getenv("DVO_PERSIST_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // (tests: a limit of 0 makes every launch give up -> the fallback runs)
+        if (launch_track_persist(pa, ppt[0], group[0], persist_grid, s)) {
+            persist_used = true;
+            DVO_HIP(hipGetLastError());
+            return DVO_OK;
+        }
+    }
     launch_track_begin(state.as<SeqState>(), log.as<dvo_track_log>(), n_seq, g.levels, s);
     const int max_it = cfg.fixed_iterations > 0 ? cfg.fixed_iterations : cfg.max_iterations;
     // Small batches: every few iterations ask the device whether anything is still active, so a converged
@@ -581,7 +634,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         DVO_HIP(hipEventRecord(ev_join[k - 1], sub_streams[k - 1]));
         DVO_HIP(hipStreamWaitEvent(s, ev_join[k - 1], 0));
     }
-    if (h_result) result_tag++;
+    if (h_result) { result_tag = (result_tag + 1) & 0x1fffff; if (result_tag == 0) result_tag = 1; }
     launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s, d_result, result_tag);
     DVO_HIP(hipGetLastError());
     return DVO_OK;
@@ -600,9 +653,21 @@ int Tracker::wait_host_result(hipStream_t s, float xi[6], float T[16])
 {
     if (!h_result) { set_error("host result not enabled"); return DVO_ERR_NOT_READY; }
     volatile int* tag = reinterpret_cast<volatile int*>(h_result + 22);
+    volatile int* gave_up = reinterpret_cast<volatile int*>(h_result + 23);
     long spins = 0;
     while (*tag != result_tag) {
         __builtin_ia32_pause();
+        if (persist_used && *gave_up == result_tag) {
+            // k_track_persist ran into its polling limit (its workgroups were not all resident: the GPU is shared with something
+            // that fills it).  Let it drain, reset its words and run this frame -- and every later one -- launch by launch.
+            DVO_HIP(hipStreamSynchronize(s));
+            DVO_HIP(hipMemset(persist_ctl.p, 0, persist_ctl.bytes));
+            persist_failed = true;
+            if (!last_obj || !last_ref) { set_error("k_track_persist gave up and the frame sets are gone"); return DVO_ERR_HIP; }
+            DVO_TRY(track(*last_obj, *last_ref, s));
+            spins = 0;
+            continue;
+        }
         if ((++spins & 0xfffff) == 0) {   // every ~1 M polls: has the stream finished (or failed) without the tag appearing?
             const hipError_t q = hipStreamQuery(s);
             if (q == hipSuccess) {
@@ -866,7 +931,7 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
 {  // system.hpp:77-93
     if (!gray || !depth || !sigma || !T_rel) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
-    if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
+    if (!trkD_ready) { trkD.prefer_persist = true; DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
     FrameInput in;   // float maps: only the rows the pyramid keeps cross PCIe (upload_rows)
     in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);
     const size_t rb = (size_t)w * sizeof(float);
@@ -893,7 +958,7 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
 
 int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* raw)
 {
-    if (!trkD_ready) { DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
+    if (!trkD_ready) { trkD.prefer_persist = true; DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
     if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
     Keyframe& frame = *depth_cur;
     frame.id = ++latest_id;

@@ -133,7 +133,15 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     void launch_gn(const GnArgs& a, int level, int count, hipStream_t s, int grid_seqs = 0) const;  // `a` views `count` sequences
     // Result hand-over for a handle that returns one pose per call (dvo_vo): k_export_poses also writes xi, T and a tag into
     // fine-grained mapped host memory, and wait_host_result() polls the tag -- no device-to-host copy, no stream synchronisation.
-    float* h_result = nullptr;   // host view: [0..5] xi, [6..21] T, [22] tag (int)
+    // One launch per track() call (k_track_persist) for a single sequence whose result is handed over through h_result: eligible
+    // when every level fits the kernel's wide reduction and shares one tile size; `persist_failed` = a launch gave up waiting
+    // (GPU oversubscribed): the handle then stays on the launch-per-iteration schedule.
+    bool prefer_persist = false;   // set before init() by the owner whose results go through enable_host_result() (VisualOdometry's sensor-depth tracker)
+    bool persist_ok = false, persist_failed = false, persist_used = false;
+    int persist_grid = 0;
+    DevBuf persist_ctl;
+    const FrameSet* last_obj = nullptr; const FrameSet* last_ref = nullptr;
+    float* h_result = nullptr;   // host view: [0..5] xi, [6..21] T, [22] tag (int), [23] tag of a persistent launch that gave up
     float* d_result = nullptr;   // device view of the same memory
     int result_tag = 0;
     int enable_host_result();

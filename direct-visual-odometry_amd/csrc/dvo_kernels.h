@@ -108,6 +108,33 @@ struct SolveArgs {
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
 };
 
+// k_track_persist: the whole of Tracker::track for ONE sequence in one launch (a dvo_vo handle).
+struct PersistLevel {
+    const float* obj_gray; const float* ref_gray; const float* ref_depth; const float* ref_wgt;
+    float wgt_const, inv_w;
+    int w, h, nblk, q256, r256;
+    Intr k;
+    GnParams prm;
+    int blk_first, blk_count, t_shift, x_org, y_org, tiles_x, t2d, level_pixels;
+};
+struct PersistArgs {
+    PersistLevel lv[DVO_MAX_LEVELS];
+    int levels;
+    SeqState* state;       // [1]
+    float* partials;       // [max nblk][32]
+    dvo_track_log* log;    // [1]
+    int* ctl;              // device memory, 64-byte aligned: the control line [0] epoch [1] next level [2] status [4..15] pose, then one arrival slot per workgroup
+    int max_iterations, fixed_iterations;
+    float min_update, min_residual;
+    float* xi_out; float* T_out;
+    float* host_result;    // fine-grained mapped host memory: [0..5] xi, [6..21] T, [22] tag, [23] tag of a launch that gave up
+    int host_tag;          // unique per launch: also the base of this launch's epoch numbers
+    int spin_limit;        // polls of the epoch word before a workgroup gives up (every wait in the kernel is bounded)
+};
+bool track_persist_available(int ppt, int group);
+int  track_persist_max_grid(int ppt, int group, int* out);   // workgroups that are co-resident on the current device
+bool launch_track_persist(const PersistArgs& p, int ppt, int group, int grid, hipStream_t s);
+
 // Tile geometry of k_track_gn: the single source of tile counts for host and device code.
 //  * raster tiles: 256 * ppt consecutive pixels (any size; tiles outside the crop rows are not live);
 //  * 2-D tiles (ppt = 4): TW = 2^shift columns x (64 / TW) * 16 rows, lane = (column, row-in-wave), wave w owns pixel rows

@@ -1065,6 +1065,190 @@ __global__ void __launch_bounds__(256) k_track_gn_fused(GnArgs a, SolveArgs sa, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_track_persist: ALL of Tracker::track (tracker.cpp:22-85: every level, every iteration) for ONE sequence in ONE launch -- what a
+// dvo_vo handle runs per frame.  A fixed grid of co-resident workgroups strides over the tiles of the current level (gn_tile, the
+// same code and tile size as k_track_gn: the same partial rows), every workgroup then takes an arrival ticket, and the LAST arriver
+// does what k_gn_solve does (second reduction stage in the fixed order, solve_finish: 6x6 solve, pose composition, stop tests,
+// log), decides what comes next (same level / next level / done) and publishes it with an epoch word; the other workgroups poll
+// that word (s_sleep between polls) and go on.  Per iteration that replaces a kernel boundary (~4 us of launch floor + cold caches
+// per launch, profiles/r03_single_*_trace.txt) by one ticket and one epoch hand-over.  Bit-identical to the launch-per-iteration
+// schedules: same tiles, same summation order, same solve_finish().
+// Safety: the grid is sized by the occupancy query (every workgroup resident), and EVERY wait is bounded -- a workgroup that polls
+// `spin_limit` times without seeing its epoch marks the launch as given up and leaves; the others then run into the same limit.
+// The host sees the mark instead of the result tag and re-runs the frame with the launch-per-iteration schedule.
+// ------------------------------------------------------------------------------------------------
+template <int PPT, int G>
+__global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
+{
+    __shared__ GnTileLds<PPT> lds;
+    __shared__ double tot[32];
+    __shared__ double part[DVO_SOLVE_GROUPS][32];
+    __shared__ int line_s[16];   // the control line as this workgroup last read / is about to write it
+    __shared__ int gave_up_s;
+    // Workgroup 0 only solves; workgroups 1 .. grid-1 evaluate tiles.  Nobody takes a contended atomic: a worker announces its tiles of
+    // step s by storing (epoch0 + s + 1) into its OWN slot of `arrive`, the solver polls the slots (one lane each); the solver
+    // publishes step s's outcome -- next level, status, and the new pose itself -- as ONE 64-byte line whose first word is
+    // (epoch0 + s + 1), which the workers poll.  The sequence's serial state (xi, exp(xi), iteration count) never leaves the
+    // solver's registers.
+    int* const ctl = p.ctl;                 // [0] epoch, [1] next level, [2] status (0 go on, 1 done), [4..15] pose
+    int* const arrive = p.ctl + 16;         // [grid]
+    const int epoch0 = p.host_tag << 10;    // epoch numbers of this launch: never equal to a value an earlier launch left behind
+    const int n_work = (int)gridDim.x - 1;
+    int level = 0, step = 0;
+    if (blockIdx.x != 0) {
+        // ---------------------------------------------------------------------------------------------- tile workers
+        const int me = (int)blockIdx.x - 1;
+        for (;;) {
+            if (threadIdx.x < 16) {   // the control line of this step (the first step is the identity pose on level 0: tracker.cpp:28)
+                int v = 0;
+                if (step == 0) {
+                    v = (threadIdx.x == 4 || threadIdx.x == 8 || threadIdx.x == 12) ? __float_as_int(1.0f) : 0;
+                } else {
+                    int polls = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int e = __builtin_amdgcn_readfirstlane(v);          // lane 0's word: the epoch of the line
+                        if (e == epoch0 + step) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++polls > p.spin_limit) { v = (threadIdx.x == 2) ? 2 : v; break; }   // bounded: give up (status 2)
+                    }
+                    // a line read while the solver was still writing it has the new epoch only if every word written before it
+                    // (release order below) is new as well; one more read after the epoch matched makes that independent of how
+                    // the 64 bytes travelled
+                    if (__builtin_amdgcn_readfirstlane(v) == epoch0 + step)
+                        v = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                line_s[threadIdx.x] = v;
+            }
+            __syncthreads();
+            const int status = line_s[2];
+            if (status != 0) {
+                if (status == 2 && threadIdx.x == 0 && p.host_result)
+                    __hip_atomic_store(reinterpret_cast<int*>(p.host_result + 23), p.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            level = line_s[1];
+            Pose pose;
+#pragma unroll
+            for (int i = 0; i < 9; i++) pose.R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[4 + i]));   // wave-uniform: SGPRs
+#pragma unroll
+            for (int i = 0; i < 3; i++) pose.t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[13 + i]));
+            const PersistLevel& L = p.lv[level];
+            GnArgs a;
+            a.obj_gray = L.obj_gray; a.ref_gray = L.ref_gray; a.ref_depth = L.ref_depth; a.ref_wgt = L.ref_wgt; a.wgt_const = L.wgt_const;
+            a.state = p.state; a.partials = p.partials; a.mask = nullptr;
+            a.w = L.w; a.h = L.h; a.nblk = L.nblk; a.inv_w = L.inv_w; a.q256 = L.q256; a.r256 = L.r256; a.k = L.k; a.prm = L.prm;
+            a.ignore_active = 1; a.list = nullptr; a.next_count = nullptr; a.n_seq = 1;
+            a.blk_first = L.blk_first; a.blk_count = L.blk_count; a.t_shift = L.t_shift; a.x_org = L.x_org; a.y_org = L.y_org;
+            a.tiles_x = L.tiles_x; a.tiles_y = 0; a.margin = 0;
+            for (int t = me; t < L.blk_count; t += n_work) {
+                float* row = p.partials + (size_t)(L.blk_first + t) * 32;
+                if constexpr (PPT == 4) {
+                    if (L.t2d) gn_tile<PPT, G, false, true>(a, pose, 0, L.blk_first + t, lds, row);
+                    else gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
+                } else {
+                    gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
+                }
+                __syncthreads();   // (the next tile reuses the LDS scratch)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's row stores have left
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the rows, before the announcement
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&arrive[me], epoch0 + step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            step++;
+            __syncthreads();   // (line_s is rewritten in the next round)
+        }
+        return;
+    }
+    // -------------------------------------------------------------------------------------------------- the solver (workgroup 0)
+    SeqState& st = p.state[0];
+    float xi[6] = {0, 0, 0, 0, 0, 0};                       // thread 0's: the sequence's serial state (tracker.cpp:28: xi = 0)
+    double Tc[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    int it_prev = 0, first = 1;
+    if (threadIdx.x == 0 && p.log) {
+        p.log[0].levels = p.levels;
+        for (int l = 0; l < DVO_MAX_LEVELS; l++) p.log[0].n_iter[l] = 0;
+    }
+    for (;;) {
+        const PersistLevel& L = p.lv[level];
+        // every worker has announced step `step` (bounded polls: one lane per worker slot)
+        if (threadIdx.x == 0) gave_up_s = 0;
+        __syncthreads();
+        for (int wk = (int)threadIdx.x; wk < n_work; wk += 256) {
+            int polls = 0;
+            while (__hip_atomic_load(&arrive[wk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch0 + step + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > p.spin_limit) { gave_up_s = 1; break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the workers' rows, after their announcements
+        __syncthreads();
+        int status = 0, nl = level;
+        if (gave_up_s) {
+            status = 2;
+        } else {
+            const int c = threadIdx.x & 31, wg = (int)(threadIdx.x >> 5);
+            if (wg < DVO_SOLVE_GROUPS && c < 29) part[wg][c] = sum_partial_class(p.partials + c, L.nblk, L.blk_first, L.blk_count, wg);
+            __syncthreads();
+            if (threadIdx.x < 32) tot[c] = c < 29 ? (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]) : 0.0;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            Pose np;
+            if (status == 0) {
+                SolveArgs sa;
+                sa.state = p.state; sa.partials = p.partials; sa.log = p.log; sa.result = nullptr; sa.counters = nullptr;
+                sa.nblk = L.nblk; sa.level = level; sa.level_pixels = L.level_pixels;
+                sa.max_iterations = p.max_iterations; sa.fixed_iterations = p.fixed_iterations;
+                sa.min_update = p.min_update; sa.min_residual = p.min_residual;
+                sa.ignore_active = first; sa.list_in = nullptr; sa.list_out = nullptr; sa.progress = nullptr; sa.n_seq = 1;
+                sa.blk_first = L.blk_first; sa.blk_count = L.blk_count;
+                const int r = solve_finish(sa, 0, st, tot, first, it_prev, xi, Tc, np);
+                it_prev = first ? 1 : it_prev + 1;       // (= st.iter)
+                if (!(r & 2)) pose_from_xi(xi, -1.0f, np);   // update rejected (NaN, tracker.cpp:47-51): the pose stays exp(-xi) of the unchanged xi
+                if (!(r & 1)) {            // the level stopped (tracker.cpp:68-73): next level, or done
+                    nl = level + 1;
+                    if (nl >= p.levels) {  // k_export_poses' work: twist + exp(xi) (system.hpp:92), also into the mapped host block
+                        status = 1;
+                        float T[16];
+                        for (int i = 0; i < 6; i++) { st.xi[i] = xi[i]; p.xi_out[i] = xi[i]; }
+                        se3_exp_f(xi, T);
+                        for (int i = 0; i < 16; i++) p.T_out[i] = T[i];
+                        if (p.host_result) {
+                            for (int i = 0; i < 6; i++) p.host_result[i] = xi[i];
+                            for (int i = 0; i < 16; i++) p.host_result[6 + i] = T[i];
+                            __hip_atomic_store(reinterpret_cast<int*>(p.host_result + 22), p.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+                }
+            } else if (p.host_result) {
+                __hip_atomic_store(reinterpret_cast<int*>(p.host_result + 23), p.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            line_s[0] = epoch0 + step + 1; line_s[1] = nl; line_s[2] = status; line_s[3] = 0;
+            for (int i = 0; i < 9; i++) line_s[4 + i] = __float_as_int(np.R[i]);
+            for (int i = 0; i < 3; i++) line_s[13 + i] = __float_as_int(np.t[i]);
+        }
+        __syncthreads();
+        // publish: words 1..15 first, then (release) the epoch word the workers poll
+        if (threadIdx.x >= 1 && threadIdx.x < 16) __hip_atomic_store(&ctl[threadIdx.x], line_s[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&ctl[0], line_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int st_now = line_s[2], nl_now = line_s[1];
+        __syncthreads();
+        if (st_now != 0) break;
+        first = (nl_now != level) ? 1 : 0;
+        level = nl_now;
+        step++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_track_level: ALL iterations of one (coarse) pyramid level for one sequence in one launch -- the loop of
 // tracker.cpp:42-74 on the device.  One workgroup per sequence: every iteration evaluates the level's live tiles with
 // gn_tile() into LDS rows, sums them exactly as k_gn_solve does (same grouping, same order: bit-identical to the
@@ -1467,6 +1651,38 @@ bool launch_track_gn_fused(const GnArgs& a0, const SolveArgs& sa0, int n_seq, in
     else if (key == 22) hipLaunchKernelGGL((k_track_gn_fused<2, 2, false>), grid, dim3(256), 0, s, a, sa, f);
     else if (key == 42 && tl.t2d) hipLaunchKernelGGL((k_track_gn_fused<4, 2, true>), grid, dim3(256), 0, s, a, sa, f);
     else if (key == 42) hipLaunchKernelGGL((k_track_gn_fused<4, 2, false>), grid, dim3(256), 0, s, a, sa, f);
+    else return false;
+    return true;
+}
+
+bool track_persist_available(int ppt, int group)
+{
+    const int key = ppt * 10 + group;
+    return key == 11 || key == 22 || key == 42;
+}
+
+int track_persist_max_grid(int ppt, int group, int* out)
+{
+    int per_cu = 0, dev = 0;
+    const int key = ppt * 10 + group;
+    hipError_t e = hipErrorInvalidValue;
+    if (key == 11) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<1, 1>, 256, 0);
+    else if (key == 22) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<2, 2>, 256, 0);
+    else if (key == 42) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<4, 2>, 256, 0);
+    if (e != hipSuccess) return DVO_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DVO_ERR_HIP;
+    *out = per_cu * prop.multiProcessorCount;
+    return DVO_OK;
+}
+
+bool launch_track_persist(const PersistArgs& p, int ppt, int group, int grid, hipStream_t s)
+{
+    const int key = ppt * 10 + group;
+    if (grid < 1) return false;
+    if (key == 11) hipLaunchKernelGGL((k_track_persist<1, 1>), dim3(grid), dim3(256), 0, s, p);
+    else if (key == 22) hipLaunchKernelGGL((k_track_persist<2, 2>), dim3(grid), dim3(256), 0, s, p);
+    else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 2>), dim3(grid), dim3(256), 0, s, p);
     else return false;
     return true;
 }

@@ -60,7 +60,10 @@ typedef struct dvo_config {
     int      track_streams;         /* 0 = auto; sub-batches of a dvo_batch tracked on concurrent HIP streams */
     int      track_adaptive;        /* 0 = auto (on), -1 = off: the host stays two iterations ahead of the GPU and stops a level's launches once no sequence is active */
     int      track_fused_tiles;     /* N > 0: levels of at most N (<= 8) 1024-px tiles run all iterations in ONE launch; 0 = off (default) */
-    int      track_single_launch;   /* 0 = auto: handles of <= 8 sequences run one launch per Gauss-Newton iteration (the workgroup that finishes a sequence's last tile solves); -1 = off */
+    int      track_single_launch;   /* 0 = auto: a dvo_vo handle's sensor-depth tracking runs in ONE launch per call (k_track_persist: co-resident workgroups,
+                                       every wait bounded, falls back by itself); other handles of <= 8 sequences run one launch per Gauss-Newton
+                                       iteration (the workgroup that finishes a sequence's last tile solves); 1 = one launch per iteration at most;
+                                       -1 = launch pairs only.  Every setting gives the same bits at the same tile size */
 } dvo_config;
 
 void        dvo_config_default(dvo_config* cfg);

@@ -681,3 +681,38 @@ def test_mapper_update_sweep(seed, w, h, gain, sig, young):
     np.testing.assert_array_equal(got_s, ref.sigma(2))
     assert got_v == v
     assert (got_d != top_d).sum() > 100, ((got_d != top_d).sum(), got_v)   # the case really exercised the update (oracle: 222 .. 2376 pixels)
+
+
+def test_single_handle_schedules_give_the_same_bits(monkeypatch):
+    """A dvo_vo handle's sensor-depth tracking on its three launch schedules -- one launch per call (k_track_persist, the default), one
+    launch per iteration (k_track_gn_fused) and launch pairs -- and on the persistent kernel's give-up path (polling limit 0: every
+    launch gives up at once and the handle re-runs the frame launch by launch): poses and per-iteration logs bit for bit."""
+    g, d, s, _ = frames(4, seed=42, sigma=0.1)
+    runs = {}
+    for name, (sl, limit) in {"persist": (0, None), "per_iteration": (1, None), "pairs": (-1, None), "persist_gives_up": (0, "0")}.items():
+        if limit is None:
+            monkeypatch.delenv("DVO_PERSIST_SPIN_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("DVO_PERSIST_SPIN_LIMIT", limit)
+        vo = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(track_single_launch=sl, gn_pixels_per_thread=4))
+        out = []
+        for i in range(4):
+            T = vo.odometrizeUsingDepth(g[i], d[i], s[i])
+            lg = vo.lastTrackLog() if i > 0 else None
+            out.append((T, lg))
+        vo.close()
+        runs[name] = out
+    monkeypatch.delenv("DVO_PERSIST_SPIN_LIMIT", raising=False)
+    ref = runs["pairs"]
+    assert sum(ref[3][1]["n_iter"]) > 8
+    for name in ("persist", "per_iteration", "persist_gives_up"):
+        for i in range(4):
+            np.testing.assert_array_equal(runs[name][i][0].view(np.uint32), ref[i][0].view(np.uint32), err_msg="%s frame %d" % (name, i))
+            if i > 0:
+                a, b = runs[name][i][1], ref[i][1]
+                assert a["n_iter"] == b["n_iter"], (name, i)
+                for l in range(4):
+                    np.testing.assert_array_equal(a["xi_after"][l], b["xi_after"][l])
+                    np.testing.assert_array_equal(a["xi_update"][l], b["xi_update"][l])
+                    np.testing.assert_array_equal(a["n_valid"][l], b["n_valid"][l])
+                    np.testing.assert_array_equal(a["residual"][l], b["residual"][l])

@@ -48,7 +48,10 @@ int main(int argc, char** argv)
             long its = 0;
             double dt = 0;
             for (int pass = 0; pass < 2; pass++) {   // pass 0 is timed; pass 1 repeats it (same frames, same results) and reads the iteration counts
-                dvo::VisualOdometry vo(K, w, h);
+                dvo_config cfg = dvo::default_config();
+                if (std::getenv("DVO_PPT")) cfg.gn_pixels_per_thread = std::atoi(std::getenv("DVO_PPT"));          // A/B knobs: tile size ...
+                if (std::getenv("DVO_SINGLE_LAUNCH")) cfg.track_single_launch = std::atoi(std::getenv("DVO_SINGLE_LAUNCH"));   // ... and schedule
+                dvo::VisualOdometry vo(K, w, h, &cfg);
                 double t0 = 0;
                 for (int k = 0; k < N + 3; k++) {
                     if (k == 3) t0 = now();
