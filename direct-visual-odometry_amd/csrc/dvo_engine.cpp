@@ -478,6 +478,11 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         if (result_tag == 0) result_tag = 1;
         pa.host_tag = result_tag;
         pa.spin_limit = 1 << 18;   // ~0.2 s of polling: far beyond any iteration, short enough that a wedged launch ends
+        if (getenv("DVO_PERSIST_TIMELINE")) {   // diagnostic: stamps of the solver and of worker 0 (tools/persist_timeline.py reads them back)
+            if (!persist_dbg.p) { DVO_TRY(persist_dbg.alloc(2 * 64 * 8 * sizeof(long long))); }
+            DVO_HIP(hipMemsetAsync(persist_dbg.p, 0, persist_dbg.bytes, s));
+            pa.dbg = persist_dbg.as<long long>();
+        }
         if (const char* e = getenv("DVO_PERSIST_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // (tests: a limit of 0 makes every launch give up -> the fallback runs)
         if (launch_track_persist(pa, ppt[0], group[0], persist_grid, s)) {
             persist_used = true;
@@ -637,6 +642,13 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
     if (h_result) { result_tag = (result_tag + 1) & 0x1fffff; if (result_tag == 0) result_tag = 1; }
     launch_export_poses(state.as<SeqState>(), xi_out.as<float>(), T_out.as<float>(), n_seq, s, d_result, result_tag);
     DVO_HIP(hipGetLastError());
+    return DVO_OK;
+}
+
+int Tracker::read_persist_timeline(long long* out)   // [2][64][8]
+{
+    if (!persist_dbg.p) return DVO_ERR_NOT_READY;
+    DVO_HIP(hipMemcpy(out, persist_dbg.p, persist_dbg.bytes, hipMemcpyDeviceToHost));
     return DVO_OK;
 }
 

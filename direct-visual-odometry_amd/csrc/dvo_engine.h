@@ -139,7 +139,8 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     bool prefer_persist = false;   // set before init() by the owner whose results go through enable_host_result() (VisualOdometry's sensor-depth tracker)
     bool persist_ok = false, persist_failed = false, persist_used = false;
     int persist_grid = 0;
-    DevBuf persist_ctl;
+    DevBuf persist_ctl, persist_dbg;
+    int read_persist_timeline(long long* out);
     const FrameSet* last_obj = nullptr; const FrameSet* last_ref = nullptr;
     float* h_result = nullptr;   // host view: [0..5] xi, [6..21] T, [22] tag (int), [23] tag of a persistent launch that gave up
     float* d_result = nullptr;   // device view of the same memory

@@ -130,6 +130,7 @@ struct PersistArgs {
     float* host_result;    // fine-grained mapped host memory: [0..5] xi, [6..21] T, [22] tag, [23] tag of a launch that gave up
     int host_tag;          // unique per launch: also the base of this launch's epoch numbers
     int spin_limit;        // polls of the epoch word before a workgroup gives up (every wait in the kernel is bounded)
+    long long* dbg;        // optional [2][64][8] wall-clock stamps (100 MHz) of the solver and of worker 0 per step (tools/persist_timeline.py)
 };
 bool track_persist_available(int ppt, int group);
 int  track_persist_max_grid(int ppt, int group, int* out);   // workgroups that are co-resident on the current device

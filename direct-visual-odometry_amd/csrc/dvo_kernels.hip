@@ -845,14 +845,22 @@ __device__ __forceinline__ double sum_partial_class(const float* p, const int nb
     const int live0 = blk_count < 0 ? 0 : blk_first, live1 = blk_count < 0 ? nblk : blk_first + blk_count;
     float v[DVO_WIDE_BATCHES][8];
 #pragma unroll
-    for (int bi = 0; bi < DVO_WIDE_BATCHES; bi++)
+    for (int bi = 0; bi < DVO_WIDE_BATCHES; bi++) {
+        // (wave-uniform: batches past the last row issue no loads -- a wave holds at most 63 loads in flight, so the 80 of a full
+        //  table are two memory round trips and the 24 of a 75-row level one: 4.0 -> 2 us of every single-stream iteration)
+        if (32 * bi < nblk) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int b = 32 * bi + g + DVO_SOLVE_GROUPS * j;
-            const bool live = (32 * bi < nblk) & (b >= live0) & (b < live1);
-            const float x = p[(size_t)(live ? b : 0) * 32];
-            v[bi][j] = live ? x : 0.0f;
+            for (int j = 0; j < 8; j++) {
+                const int b = 32 * bi + g + DVO_SOLVE_GROUPS * j;
+                const bool live = (b >= live0) & (b < live1);
+                const float x = p[(size_t)(live ? b : 0) * 32];
+                v[bi][j] = live ? x : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[bi][j] = 0.0f;
         }
+    }
     double sg = 0.0;
 #pragma unroll
     for (int bi = 0; bi < DVO_WIDE_BATCHES; bi++)
@@ -1090,7 +1098,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
     // publishes step s's outcome -- next level, status, and the new pose itself -- as ONE 64-byte line whose first word is
     // (epoch0 + s + 1), which the workers poll.  The sequence's serial state (xi, exp(xi), iteration count) never leaves the
     // solver's registers.
-    int* const ctl = p.ctl;                 // [0] epoch, [1] next level, [2] status (0 go on, 1 done), [4..15] pose
+    int* const ctl = p.ctl;                 // [0] epoch, [1] next level, [2] status (0 go on, 1 done), [3..14] pose, [15] epoch again
     int* const arrive = p.ctl + 16;         // [grid]
     const int epoch0 = p.host_tag << 10;    // epoch numbers of this launch: never equal to a value an earlier launch left behind
     const int n_work = (int)gridDim.x - 1;
@@ -1102,25 +1110,25 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             if (threadIdx.x < 16) {   // the control line of this step (the first step is the identity pose on level 0: tracker.cpp:28)
                 int v = 0;
                 if (step == 0) {
-                    v = (threadIdx.x == 4 || threadIdx.x == 8 || threadIdx.x == 12) ? __float_as_int(1.0f) : 0;
+                    v = (threadIdx.x == 3 || threadIdx.x == 7 || threadIdx.x == 11) ? __float_as_int(1.0f) : 0;   // (pose words 3..14: R row major, t)
                 } else {
                     int polls = 0;
                     for (;;) {
                         v = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int e = __builtin_amdgcn_readfirstlane(v);          // lane 0's word: the epoch of the line
-                        if (e == epoch0 + step) break;
-                        __builtin_amdgcn_s_sleep(1);
+                        // The line is complete when its FIRST word (the epoch, stored last, after a release) and its LAST word (a copy
+                        // of the epoch, stored with the payload) both carry this step's number: whatever order the 64 bytes were
+                        // fetched in, a current first word means every store before the release had landed when it was read, and a
+                        // current last word means the payload store itself had landed when the other end was read.
+                        const int e0 = __builtin_amdgcn_readlane(v, 0), e15 = __builtin_amdgcn_readlane(v, 15);
+                        if (e0 == epoch0 + step && e15 == epoch0 + step) break;
                         if (++polls > p.spin_limit) { v = (threadIdx.x == 2) ? 2 : v; break; }   // bounded: give up (status 2)
                     }
-                    // a line read while the solver was still writing it has the new epoch only if every word written before it
-                    // (release order below) is new as well; one more read after the epoch matched makes that independent of how
-                    // the 64 bytes travelled
-                    if (__builtin_amdgcn_readfirstlane(v) == epoch0 + step)
-                        v = __hip_atomic_load(&ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 line_s[threadIdx.x] = v;
             }
             __syncthreads();
+            const bool stamp = p.dbg && me == 0 && threadIdx.x == 0 && step < 64;
+            if (stamp) p.dbg[(64 + step) * 8 + 0] = wall_clock64();   // line seen
             const int status = line_s[2];
             if (status != 0) {
                 if (status == 2 && threadIdx.x == 0 && p.host_result)
@@ -1130,9 +1138,9 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             level = line_s[1];
             Pose pose;
 #pragma unroll
-            for (int i = 0; i < 9; i++) pose.R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[4 + i]));   // wave-uniform: SGPRs
+            for (int i = 0; i < 9; i++) pose.R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[3 + i]));   // wave-uniform: SGPRs
 #pragma unroll
-            for (int i = 0; i < 3; i++) pose.t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[13 + i]));
+            for (int i = 0; i < 3; i++) pose.t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(line_s[12 + i]));
             const PersistLevel& L = p.lv[level];
             GnArgs a;
             a.obj_gray = L.obj_gray; a.ref_gray = L.ref_gray; a.ref_depth = L.ref_depth; a.ref_wgt = L.ref_wgt; a.wgt_const = L.wgt_const;
@@ -1153,11 +1161,13 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's row stores have left
             __syncthreads();
+            if (stamp) p.dbg[(64 + step) * 8 + 1] = wall_clock64();   // tiles done
             if (threadIdx.x == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the rows, before the announcement
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&arrive[me], epoch0 + step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (stamp) p.dbg[(64 + step) * 8 + 2] = wall_clock64();   // announced
             step++;
             __syncthreads();   // (line_s is rewritten in the next round)
         }
@@ -1177,15 +1187,18 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
         // every worker has announced step `step` (bounded polls: one lane per worker slot)
         if (threadIdx.x == 0) gave_up_s = 0;
         __syncthreads();
+        const bool stamp = p.dbg && threadIdx.x == 0 && step < 64;
+        if (stamp) p.dbg[step * 8 + 0] = wall_clock64();   // starts waiting
         for (int wk = (int)threadIdx.x; wk < n_work; wk += 256) {
             int polls = 0;
             while (__hip_atomic_load(&arrive[wk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch0 + step + 1) {
-                __builtin_amdgcn_s_sleep(1);
                 if (++polls > p.spin_limit) { gave_up_s = 1; break; }
             }
         }
+        if (stamp) p.dbg[step * 8 + 1] = wall_clock64();   // own slots seen
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the workers' rows, after their announcements
         __syncthreads();
+        if (stamp) p.dbg[step * 8 + 2] = wall_clock64();   // everybody arrived, fence done
         int status = 0, nl = level;
         if (gave_up_s) {
             status = 2;
@@ -1196,6 +1209,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             if (threadIdx.x < 32) tot[c] = c < 29 ? (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]) : 0.0;
             __syncthreads();
         }
+        if (stamp) p.dbg[step * 8 + 3] = wall_clock64();   // rows summed
         if (threadIdx.x == 0) {
             Pose np;
             if (status == 0) {
@@ -1227,9 +1241,10 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             } else if (p.host_result) {
                 __hip_atomic_store(reinterpret_cast<int*>(p.host_result + 23), p.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            line_s[0] = epoch0 + step + 1; line_s[1] = nl; line_s[2] = status; line_s[3] = 0;
-            for (int i = 0; i < 9; i++) line_s[4 + i] = __float_as_int(np.R[i]);
-            for (int i = 0; i < 3; i++) line_s[13 + i] = __float_as_int(np.t[i]);
+            if (stamp) { p.dbg[step * 8 + 4] = wall_clock64(); p.dbg[step * 8 + 6] = level; }   // solved
+            line_s[0] = epoch0 + step + 1; line_s[1] = nl; line_s[2] = status; line_s[15] = epoch0 + step + 1;
+            for (int i = 0; i < 9; i++) line_s[3 + i] = __float_as_int(np.R[i]);
+            for (int i = 0; i < 3; i++) line_s[12 + i] = __float_as_int(np.t[i]);
         }
         __syncthreads();
         // publish: words 1..15 first, then (release) the epoch word the workers poll
@@ -1239,6 +1254,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) __hip_atomic_store(&ctl[0], line_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (stamp) p.dbg[step * 8 + 5] = wall_clock64();   // published
         const int st_now = line_s[2], nl_now = line_s[1];
         __syncthreads();
         if (st_now != 0) break;
@@ -1668,7 +1684,7 @@ int track_persist_max_grid(int ppt, int group, int* out)
     hipError_t e = hipErrorInvalidValue;
     if (key == 11) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<1, 1>, 256, 0);
     else if (key == 22) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<2, 2>, 256, 0);
-    else if (key == 42) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<4, 2>, 256, 0);
+    else if (key == 42) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<4, 4>, 256, 0);
     if (e != hipSuccess) return DVO_ERR_HIP;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DVO_ERR_HIP;
@@ -1680,9 +1696,11 @@ bool launch_track_persist(const PersistArgs& p, int ppt, int group, int grid, hi
 {
     const int key = ppt * 10 + group;
     if (grid < 1) return false;
+    // (the gather group only sets how many pixels' gathers are in flight together, never a result: this kernel runs one wave per SIMD
+    //  whatever it does, so it takes all of a thread's pixels at once)
     if (key == 11) hipLaunchKernelGGL((k_track_persist<1, 1>), dim3(grid), dim3(256), 0, s, p);
     else if (key == 22) hipLaunchKernelGGL((k_track_persist<2, 2>), dim3(grid), dim3(256), 0, s, p);
-    else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 2>), dim3(grid), dim3(256), 0, s, p);
+    else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 4>), dim3(grid), dim3(256), 0, s, p);
     else return false;
     return true;
 }
