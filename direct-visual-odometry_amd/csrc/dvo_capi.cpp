@@ -176,7 +176,7 @@ int dvo_vo_last_frame_pose(const dvo_vo* vo, int* id, float xi[6], float rel_xi[
 }
 
 // diagnostic (DVO_PERSIST_TIMELINE=1): wall-clock stamps [2][64][8] of the last k_track_persist launch of the sensor-depth tracker
-extern "C" int dvo_debug_persist_timeline(dvo_vo* vo, long long* out)
+int dvo_debug_persist_timeline(dvo_vo* vo, long long* out)
 {
     if (!vo || !out) return DVO_ERR_BAD_ARGUMENT;
     return vo->impl.trkD.read_persist_timeline(out);

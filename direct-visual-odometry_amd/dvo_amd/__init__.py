@@ -82,7 +82,7 @@ EXPORTS = [
     "dvo_config_default", "dvo_version", "dvo_status_string", "dvo_last_error", "dvo_device_count",
     "dvo_vo_create", "dvo_vo_destroy", "dvo_vo_set_initial_depth", "dvo_vo_init_keyframe", "dvo_vo_odometrize",
     "dvo_vo_odometrize_depth", "dvo_vo_odometrize_raw", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
-    "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log",
+    "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log", "dvo_debug_persist_timeline",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
     "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
     "dvo_batch_push_raw_device", "dvo_batch_prefetch_raw_device", "dvo_batch_push_raw_host", "dvo_batch_odometrize_raw_device",

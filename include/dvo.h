@@ -118,6 +118,9 @@ typedef struct dvo_track_log {
     float xi_update[DVO_MAX_LEVELS][DVO_MAX_ITERATIONS][6];  /* Outcome::xi_update of the iteration (optimize.cpp:98), before the composition */
 } dvo_track_log;
 int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log);
+/* Diagnostic (environment DVO_PERSIST_TIMELINE=1): wall-clock stamps (100 MHz) [2][64][8] the solver workgroup and worker 0 of the last
+ * one-launch-per-call tracking kernel left per Gauss-Newton step (tools/persist_timeline.py prints them).  DVO_ERR_NOT_READY otherwise. */
+int dvo_debug_persist_timeline(dvo_vo* vo, long long* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched tracking: n_seq independent sequences on one GPU, frame-to-frame with sensor depth
