@@ -278,6 +278,7 @@ struct MonoBatch {
     FrameSet ref, frm;       // newest keyframe of every sequence; the frame being processed
     DevBuf ref_age, frm_age, owner, tmp, ring_gray, hist_xi, ages, meta, init_depth, init_sigma;
     DevBuf xi_world, T_world, is_key;
+    DevBuf need_list;        // [0] = number of sequences that create a keyframe on this frame, [4..] their ids (k_mono_decide)
     float* depth_alt = nullptr;  // the second top-level depth buffer of `ref` (k_regularize_redecimate ping-pongs between the two)
     int latest_id = -1;      // Frame::latest_id, frame.cpp:5 (all sequences advance in lockstep)
     bool have_init = false;

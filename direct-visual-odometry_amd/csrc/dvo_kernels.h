@@ -232,6 +232,7 @@ struct UpdateArgs {
     uint32_t seed;
     Intr k;
     float K9[9];
+    int k_sparse = 0;        // K9 = [fx 0 cx; 0 fy cy; 0 0 1] exactly (set by launch_depth_update): depthEstimate skips the products with the zeros
     Pose rel_pose;           // exp(+rel_xi)          } operator level only (meta == nullptr)
     float rel_tz;            // rel_xi[2]             }
     int* valid_updates;      //                       }
@@ -246,6 +247,12 @@ struct PropArgs {      // Implement::propagate (implement.cpp:217-256)
     const MonoSeq* meta;     // per-sequence pose + need flag; nullptr: `pose` / `tz` below, unconditional
     Pose pose; float tz;
     float inv_w = 0.0f;      // 1 / w (set by launch_propagate_batch)
+    // Compact list of the sequences that take this branch ([0] = count, [4..] = ids, written by k_mono_decide): the grid then holds
+    // min(n_seq, n_slots) sequence slots and slot j works through list entries j, j + n_slots, ... -- on a typical frame a sixth of
+    // the sequences create a keyframe, and a workgroup that only finds out it has nothing to do costs as much to dispatch as one
+    // that works.  nullptr: every sequence (or its `meta` flag).
+    const int* need_list = nullptr;
+    int n_slots = 0;
 };
 
 #define DVO_PROMOTE_MAX_SEG 8
@@ -259,11 +266,13 @@ struct PromoteArgs {   // a tracked frame becomes the newest keyframe of the seq
     int npix, R;
     const MonoSeq* meta;
     int all;                 // 1: every sequence (first frame), 0: need flag
+    const int* need_list = nullptr;   // as PropArgs::need_list (all == 0 only)
+    int n_slots = 0;
 };
 
 struct MonoRef { float ref_xi[6]; int ref_id, n_total, valid; };   // reference keyframe of a single dvo_vo handle (kernel argument)
 void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
-                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s);
+                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s, int* need_list = nullptr);
 void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,
                         hipStream_t s);
 void launch_age_table(const AgeTableArgs& a, hipStream_t s);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void split_row(int i, int w, float inv_w, int& x, int
 // rel_pose <- exp(+rel_xi), T_world <- exp(frame_xi).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation,
-                                                    int max_frames, float* xi_world, float* T_world, int* is_key, MonoRef host_ref)
+                                                    int max_frames, float* xi_world, float* T_world, int* is_key, MonoRef host_ref, int* need_list)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n_seq) return;
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(64) k_mono_decide(MonoSeq* meta, const SeqStat
     m.frame_id = frame_id;
     m.need = need;
     m.valid_updates = 0;
+    if (need && need_list) need_list[4 + atomicAdd(&need_list[0], 1)] = s;   // (the order of the list changes no result: sequences are independent)
     if (xi_world) for (int i = 0; i < 6; i++) xi_world[s * 6 + i] = fx[i];
     if (T_world) for (int i = 0; i < 16; i++) T_world[s * 16 + i] = T[i];
     if (is_key) is_key[s] = need;
@@ -131,72 +132,92 @@ __global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
 // (four pixels per thread: on most frames most sequences take the other branch, and a workgroup that only finds that out costs
 //  as much to dispatch as one that works -- a quarter of the workgroups)
 #define DVO_PROP_PER_THREAD 4
+#define DVO_LIST_SLOTS 1024   /* sequence slots of a launch that works through a compact list (PropArgs::need_list) */
 __device__ __forceinline__ int prop_chunk(int& seq)   // first pixel of this thread (stride 256), sequence of the workgroup
 {
     seq = grid_seq();
     return (int)blockIdx.x * (256 * DVO_PROP_PER_THREAD) + (int)threadIdx.x;
 }
 
+// The sequences a workgroup of the propagate / promote kernels works through: with a list, slot j takes entries j, j + n_slots, ...;
+// without one, its own sequence (when the `need` flag says so).  Returns false when there is nothing (more) to do.
+__device__ __forceinline__ bool next_listed_seq(const int* list, int n_slots, int n_seq, const MonoSeq* meta, int& cursor, int& seq)
+{
+    if (list) {
+        if (cursor < 0) cursor = grid_seq(); else cursor += n_slots;
+        if (cursor >= list[0]) return false;
+        seq = list[4 + cursor];
+        return true;
+    }
+    if (cursor >= 0) return false;
+    cursor = 0;
+    seq = grid_seq();
+    return seq < n_seq && !(meta && !meta[seq].need);
+}
+
 __global__ void __launch_bounds__(256) k_propagate_init(PropArgs a)
 {
-    int seq;
+    int seq, cursor = -1;
     const int n = a.w * a.h, i0 = prop_chunk(seq);
-    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
+    while (next_listed_seq(a.need_list, a.n_slots, a.n_seq, a.meta, cursor, seq)) {
 #pragma unroll
-    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
-        const int i = i0 + k * 256;
-        if (i >= n) break;
-        const size_t o = (size_t)seq * n + i;
-        a.depth[o] = 1.0f; a.sigma[o] = 1.0f; a.age[o] = 0.0f; a.owner[o] = -1;
+        for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+            const int i = i0 + k * 256;
+            if (i >= n) break;
+            const size_t o = (size_t)seq * n + i;
+            a.depth[o] = 1.0f; a.sigma[o] = 1.0f; a.age[o] = 0.0f; a.owner[o] = -1;
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_propagate_owner(PropArgs a)
 {
-    int seq;
+    int seq, cursor = -1;
     const int w = a.w, h = a.h, n = w * h, i0 = prop_chunk(seq);
-    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
-    const Pose pose = a.meta ? a.meta[seq].rel_pose : a.pose;   // wave-uniform
+    while (next_listed_seq(a.need_list, a.n_slots, a.n_seq, a.meta, cursor, seq)) {
+        const Pose pose = a.meta ? a.meta[seq].rel_pose : a.pose;   // wave-uniform
 #pragma unroll
-    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
-        const int i = i0 + k * 256;
-        if (i >= n) break;
-        int x, y;
-        split_row(i, w, a.inv_w, x, y);
-        const float rd = a.ref_depth[(size_t)seq * n + i];
-        if (is_epsilon(rd)) continue;
-        float pu, pv;
-        warp(pose, a.k, (float)x, (float)y, rd, pu, pv);
-        int qx, qy;
-        if (!round_coord(pu, qx) || !round_coord(pv, qy)) continue;
-        if (qx < 0 || w <= qx || qy < 0 || h <= qy) continue;
-        atomicMax(&a.owner[(size_t)seq * n + qy * w + qx], i);
+        for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+            const int i = i0 + k * 256;
+            if (i >= n) break;
+            int x, y;
+            split_row(i, w, a.inv_w, x, y);
+            const float rd = a.ref_depth[(size_t)seq * n + i];
+            if (is_epsilon(rd)) continue;
+            float pu, pv;
+            warp(pose, a.k, (float)x, (float)y, rd, pu, pv);
+            int qx, qy;
+            if (!round_coord(pu, qx) || !round_coord(pv, qy)) continue;
+            if (qx < 0 || w <= qx || qy < 0 || h <= qy) continue;
+            atomicMax(&a.owner[(size_t)seq * n + qy * w + qx], i);
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_propagate_pull(PropArgs a)
 {
-    int seq;
+    int seq, cursor = -1;
     const int n = a.w * a.h, o0 = prop_chunk(seq);
-    if (seq >= a.n_seq || (a.meta && !a.meta[seq].need)) return;
-    const float tz = a.meta ? a.meta[seq].rel_xi[2] : a.tz;
-    const size_t base = (size_t)seq * n;
+    while (next_listed_seq(a.need_list, a.n_slots, a.n_seq, a.meta, cursor, seq)) {
+        const float tz = a.meta ? a.meta[seq].rel_xi[2] : a.tz;
+        const size_t base = (size_t)seq * n;
 #pragma unroll
-    for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
-        const int o = o0 + k * 256;
-        if (o >= n) break;
-        const int i = a.owner[base + o];
-        if (i < 0) continue;
-        const float rd = a.ref_depth[base + i];
-        float s = a.ref_sigma[base + i];
-        const float d0 = rd < 0.01f ? 0.01f : rd;
-        const float d1 = d0 + tz;
-        const float q = d1 / d0;
-        const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
-        s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
-        a.depth[base + o] = d1 < 0.0f ? 0.0f : d1;
-        a.sigma[base + o] = s;
-        a.age[base + o] = a.ref_age[base + i] + 1.0f;
+        for (int k = 0; k < DVO_PROP_PER_THREAD; k++) {
+            const int o = o0 + k * 256;
+            if (o >= n) break;
+            const int i = a.owner[base + o];
+            if (i < 0) continue;
+            const float rd = a.ref_depth[base + i];
+            float s = a.ref_sigma[base + i];
+            const float d0 = rd < 0.01f ? 0.01f : rd;
+            const float d1 = d0 + tz;
+            const float q = d1 / d0;
+            const float q4 = q * (q * (q * q));          // math::pow(q, 4), util.hpp:19-27
+            s = sqrtf(fmaf(q4, s * s, 0.06f * 0.06f));   // implement.cpp:246-247
+            a.depth[base + o] = d1 < 0.0f ? 0.0f : d1;
+            a.sigma[base + o] = s;
+            a.age[base + o] = a.ref_age[base + i] + 1.0f;
+        }
     }
 }
 
@@ -434,12 +455,23 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
         double Rq[3], KRq[3], Kt[3];
         for (int r = 0; r < 3; r++)
             Rq[r] = (double)born.pose.R[3 * r] * q0 + (double)born.pose.R[3 * r + 1] * q1 + (double)born.pose.R[3 * r + 2] * q2;
-        for (int r = 0; r < 3; r++) {
-            KRq[r] = (double)a.K9[3 * r] * Rq[0] + (double)a.K9[3 * r + 1] * Rq[1] + (double)a.K9[3 * r + 2] * Rq[2];
-            Kt[r] = (double)a.K9[3 * r] * t[0] + (double)a.K9[3 * r + 1] * t[1] + (double)a.K9[3 * r + 2] * t[2];
+        if (a.k_sparse) {
+            // K = [fx 0 cx; 0 fy cy; 0 0 1]: a product with an exact zero adds an exact zero, so (fx x + 0 y) + cx z is fx x + cx z and
+            // (0 x + 0 y) + 1 z is z -- the same doubles as the three-term rows below (for finite x, y, z: they are), 12 instead of 30
+            // fp64 operations per pixel for K R q and K t.
+            const double fx = (double)a.K9[0], cx = (double)a.K9[2], fy = (double)a.K9[4], cy = (double)a.K9[5];
+            KRq[0] = fx * Rq[0] + cx * Rq[2]; KRq[1] = fy * Rq[1] + cy * Rq[2]; KRq[2] = Rq[2];
+            Kt[0] = fx * t[0] + cx * t[2]; Kt[1] = fy * t[1] + cy * t[2]; Kt[2] = t[2];
+        } else {
+            for (int r = 0; r < 3; r++) {
+                KRq[r] = (double)a.K9[3 * r] * Rq[0] + (double)a.K9[3 * r + 1] * Rq[1] + (double)a.K9[3 * r + 2] * Rq[2];
+                Kt[r] = (double)a.K9[3 * r] * t[0] + (double)a.K9[3 * r + 1] * t[1] + (double)a.K9[3 * r + 2] * t[2];
+            }
         }
         double aa = 0.0, ab = 0.0;
-        for (int r = 0; r < 3; r++) {
+        // (sparse K: the third components are Rq[2] * 1 - Rq[2] and t[2] * 1 - t[2], exact zeros whose products add exact zeros)
+        const int nr = a.k_sparse ? 2 : 3;
+        for (int r = 0; r < nr; r++) {
             const double va = Rq[2] * xi3[r] - KRq[r];
             const double vb = t[2] * xi3[r] - Kt[r];
             aa += va * va;
@@ -565,30 +597,30 @@ __global__ void __launch_bounds__(256) k_promote(PromoteArgs a)
     total /= VEC;        // in units of VEC floats
     // 2048 units per workgroup: most sequences do not create a keyframe on a given frame, and a workgroup that only finds that
     // out costs as much to dispatch as one that copies -- fewer, fatter workgroups
-    const int seq = grid_seq();
-    if (seq >= a.n_seq) return;
-    const MonoSeq& m = a.meta[seq];
-    if (!a.all && !m.need) return;
-    const int slot = a.all ? 0 : m.n_total % a.R;   // (k_mono_commit increments n_total AFTER this kernel)
+    int seq, cursor = -1;
     const int i0 = (int)blockIdx.x * (256 * DVO_PROMOTE_PER_THREAD) + (int)threadIdx.x;
+    while (next_listed_seq(a.all ? nullptr : a.need_list, a.n_slots, a.n_seq, a.all ? nullptr : a.meta, cursor, seq)) {
+        const MonoSeq& m = a.meta[seq];
+        const int slot = a.all ? 0 : m.n_total % a.R;   // (k_mono_commit increments n_total AFTER this kernel)
 #pragma unroll
-    for (int k = 0; k < DVO_PROMOTE_PER_THREAD; k++) {
-        int i = i0 + k * 256;
-        if (i >= total) break;
-        bool done = false;
-        for (int g = 0; g < a.n_seg; g++) {
-            const int cnt = a.count[g] / VEC;
-            if (i < cnt) {
-                const size_t o = (size_t)seq * cnt + i;
-                reinterpret_cast<fvec*>(a.dst[g])[o] = reinterpret_cast<const fvec*>(a.src[g])[o];
-                done = true;
-                break;
+        for (int k = 0; k < DVO_PROMOTE_PER_THREAD; k++) {
+            int i = i0 + k * 256;
+            if (i >= total) break;
+            bool done = false;
+            for (int g = 0; g < a.n_seg; g++) {
+                const int cnt = a.count[g] / VEC;
+                if (i < cnt) {
+                    const size_t o = (size_t)seq * cnt + i;
+                    reinterpret_cast<fvec*>(a.dst[g])[o] = reinterpret_cast<const fvec*>(a.src[g])[o];
+                    done = true;
+                    break;
+                }
+                i -= cnt;
             }
-            i -= cnt;
-        }
-        if (!done) {
-            const int cnt = a.npix / VEC;
-            reinterpret_cast<fvec*>(a.ring_gray)[((size_t)seq * a.R + slot) * cnt + i] = reinterpret_cast<const fvec*>(a.gray_top)[(size_t)seq * cnt + i];
+            if (!done) {
+                const int cnt = a.npix / VEC;
+                reinterpret_cast<fvec*>(a.ring_gray)[((size_t)seq * a.R + slot) * cnt + i] = reinterpret_cast<const fvec*>(a.gray_top)[(size_t)seq * cnt + i];
+            }
         }
     }
 }
@@ -602,12 +634,12 @@ __global__ void __launch_bounds__(256) k_broadcast(const float* __restrict__ src
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
 void launch_mono_decide(MonoSeq* meta, const SeqState* state, int n_seq, int frame_id, float min_translation, int max_frames,
-                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s)
+                        float* xi_world, float* T_world, int* is_key, const MonoRef* host_ref, hipStream_t s, int* need_list)
 {
     MonoRef r;
     if (host_ref) r = *host_ref; else { for (int i = 0; i < 6; i++) r.ref_xi[i] = 0.0f; r.ref_id = 0; r.n_total = 0; r.valid = 0; }
     hipLaunchKernelGGL(k_mono_decide, dim3(cdiv_u(n_seq, 64)), dim3(64), 0, s, meta, state, n_seq, frame_id, min_translation, max_frames,
-                       xi_world, T_world, is_key, r);
+                       xi_world, T_world, is_key, r, need_list);
 }
 
 void launch_mono_commit(MonoSeq* meta, float* hist_xi, int n_seq, int R, int all, int frame_id, float* xi_world, float* T_world, int* is_key,
@@ -629,8 +661,12 @@ void launch_promote(const PromoteArgs& a, hipStream_t s)
         total += a.count[g];
         vec = vec && (a.count[g] % 4) == 0 && (reinterpret_cast<uintptr_t>(a.src[g]) % 16) == 0 && (reinterpret_cast<uintptr_t>(a.dst[g]) % 16) == 0;
     }
-    if (vec) hipLaunchKernelGGL(k_promote<4>, seq_grid(cdiv_u(total / 4, 256 * DVO_PROMOTE_PER_THREAD), (unsigned)a.n_seq), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_promote<1>, seq_grid(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD), (unsigned)a.n_seq), dim3(256), 0, s, a);
+    PromoteArgs b = a;
+    const bool listed = !a.all && a.need_list != nullptr;
+    b.n_slots = listed ? (a.n_seq < DVO_LIST_SLOTS ? a.n_seq : DVO_LIST_SLOTS) : 0;
+    const unsigned gs = listed ? (unsigned)b.n_slots : (unsigned)a.n_seq;
+    if (vec) hipLaunchKernelGGL(k_promote<4>, seq_grid(cdiv_u(total / 4, 256 * DVO_PROMOTE_PER_THREAD), gs), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(k_promote<1>, seq_grid(cdiv_u(total, 256 * DVO_PROMOTE_PER_THREAD), gs), dim3(256), 0, s, b);
 }
 
 void launch_broadcast(const float* src, float* dst, int count, int n_seq, hipStream_t s)
@@ -642,7 +678,8 @@ void launch_propagate_batch(const PropArgs& a0, hipStream_t s)
 {
     PropArgs a = a0;
     a.inv_w = 1.0f / (float)a.w;
-    const dim3 grid = seq_grid(cdiv_u(a.w * a.h, 256 * DVO_PROP_PER_THREAD), (unsigned)a.n_seq);
+    a.n_slots = a.need_list ? (a.n_seq < DVO_LIST_SLOTS ? a.n_seq : DVO_LIST_SLOTS) : 0;
+    const dim3 grid = seq_grid(cdiv_u(a.w * a.h, 256 * DVO_PROP_PER_THREAD), a.need_list ? (unsigned)a.n_slots : (unsigned)a.n_seq);
     hipLaunchKernelGGL(k_propagate_init, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_owner, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_propagate_pull, grid, dim3(256), 0, s, a);
@@ -682,6 +719,7 @@ void launch_depth_update(const UpdateArgs& a0, hipStream_t s)
     const int ww = a.crop ? ((a.w - 1 < 144 ? a.w - 1 : 144) - 16 + 1) : a.w, wh = a.crop ? ((a.h - 1 < 108 ? a.h - 1 : 108) - 12 + 1) : a.h;
     if (ww <= 0 || wh <= 0) return;
     a.inv_ww = 1.0f / (float)ww;
+    a.k_sparse = (a.K9[1] == 0.0f && a.K9[3] == 0.0f && a.K9[6] == 0.0f && a.K9[7] == 0.0f && a.K9[8] == 1.0f) ? 1 : 0;
     hipLaunchKernelGGL(k_depth_update, seq_grid(cdiv_u(ww * wh, 256), (unsigned)a.n_seq), dim3(256), 0, s, a);
 }
 

@@ -61,6 +61,7 @@ int MonoBatch::init(int n, const float K9[9], int w, int h, int ring, const dvo_
     DVO_TRY(xi_world.alloc(sizeof(float) * 6 * (size_t)n));
     DVO_TRY(T_world.alloc(sizeof(float) * 16 * (size_t)n));
     DVO_TRY(is_key.alloc(sizeof(int) * (size_t)n));
+    DVO_TRY(need_list.alloc(sizeof(int) * ((size_t)n + 4)));
     DVO_HIP(hipMemset(meta.p, 0, meta.bytes));
     DVO_HIP(hipMemset(hist_xi.p, 0, hist_xi.bytes));
     return DVO_OK;
@@ -172,8 +173,9 @@ int MonoBatch::odometrize(const FrameInput& in)
     { TraceRange tr("mono pyramid"); build_pyramid(frm, gin, stream); }           // Frame(gray, K, 3, 2)
     { TraceRange tr("mono track"); DVO_TRY(trk.track(frm, ref, stream)); }           // system.hpp:57
     TraceRange tr_map("mono map (decide, propagate | update, promote, regularize)");
+    DVO_HIP(hipMemsetAsync(need_list.p, 0, 4 * sizeof(int), stream));
     launch_mono_decide(m, trk.state.as<SeqState>(), n_seq, frame_id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
-                       xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), nullptr, stream);
+                       xi_world.as<float>(), T_world.as<float>(), is_key.as<int>(), nullptr, stream, need_list.as<int>());
     // ---- Mapper::estimate (mapper.cpp:16-33), both branches launched, each sequence takes its own ----
     {   // need: propagate the reference maps into the frame (mapper.cpp:62-74) ...
         PropArgs a;
@@ -182,6 +184,7 @@ int MonoBatch::odometrize(const FrameInput& in)
         a.owner = owner.as<int>();
         a.w = tw; a.h = th; a.n_seq = n_seq; a.k = g.k[T]; a.meta = m;
         memset(&a.pose, 0, sizeof a.pose); a.tz = 0.0f;
+        a.need_list = need_list.as<int>();
         if (pe) DVO_HIP(hipEventRecord(pe->e[0], stream));
         launch_propagate_batch(a, stream);
         if (pe) DVO_HIP(hipEventRecord(pe->e[1], stream));
@@ -215,6 +218,7 @@ int MonoBatch::odometrize(const FrameInput& in)
         pa.src[sgi] = frm_age.as<float>(); pa.dst[sgi] = ref_age.as<float>(); pa.count[sgi] = np; sgi++;
         pa.n_seg = sgi; pa.n_seq = n_seq; pa.gray_top = frm.gray[T]; pa.ring_gray = ring_gray.as<float>(); pa.npix = np; pa.R = R;
         pa.meta = m; pa.all = 0;
+        pa.need_list = need_list.as<int>();
         launch_promote(pa, stream);
         launch_mono_commit(m, hist_xi.as<float>(), n_seq, R, 0, frame_id, nullptr, nullptr, nullptr, stream);
     }
