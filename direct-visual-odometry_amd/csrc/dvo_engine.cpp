@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include <dlfcn.h>
 
@@ -728,8 +729,22 @@ int VisualOdometry::fetch_log()
     return DVO_OK;
 }
 
+int VisualOdometry::upload_streams()
+{
+    if (ustream[0]) return DVO_OK;
+    for (int i = 0; i < 2; i++) {
+        DVO_HIP(hipStreamCreateWithFlags(&ustream[i], hipStreamNonBlocking));
+        DVO_HIP(hipEventCreateWithFlags(&uevent[i], hipEventDisableTiming));
+    }
+    return DVO_OK;
+}
+
 VisualOdometry::~VisualOdometry()
 {
+    for (int i = 0; i < 2; i++) {
+        if (ustream[i]) { (void)hipStreamSynchronize(ustream[i]); (void)hipStreamDestroy(ustream[i]); }
+        if (uevent[i]) (void)hipEventDestroy(uevent[i]);
+    }
     if (h_pin) (void)hipHostFree(h_pin);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -947,11 +962,30 @@ int VisualOdometry::odometrize_depth(const float* gray, const float* depth, cons
     FrameInput in;   // float maps: only the rows the pyramid keeps cross PCIe (upload_rows)
     in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);
     const size_t rb = (size_t)w * sizeof(float);
+    // Tracking this frame needs its GRAY pyramid only (obj) -- depth, sigma and the weight come from the reference, the previous frame
+    // (tracker.cpp:22-41).  So only the gray map's copy + pyramid sit on the critical path; the depth and sigma maps go up on a side
+    // stream and their pyramid is built there WHILE this frame is tracked (three strided copies in a row were 98 us between one frame's
+    // tracking and the next, profiles/r03_single_hip_trace.txt; one is ~30).  The next call makes the tracking stream wait for that
+    // build (this frame is then the reference); this call returns only after the side copies have read the caller's buffers.
+    DVO_TRY(upload_streams());
+    if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
+    if (side_built) DVO_HIP(hipStreamWaitEvent(stream, uevent[1], 0));   // the reference's depth / sigma / weight pyramid (built during the previous call)
     DVO_TRY(upload_rows(in_gray.p, gray, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
-    DVO_TRY(upload_rows(in_depth.p, depth, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
-    DVO_TRY(upload_rows(in_sigma.p, sigma, rb, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
-    in.gray = in_gray.as<float>(); in.depth = in_depth.as<float>(); in.sigma = in_sigma.as<float>();
-    return odometrize_depth_staged(T_rel, &in);
+    Keyframe* const target = depth_cur.get();
+    const bool dec = in.rows_decimated;
+    const std::function<int()> side = [&]() -> int {   // queued after this frame's pyramid + tracking launches: those are the critical path
+        DVO_TRY(upload_rows(in_depth.p, depth, rb, h, 1, geoD.culls, dec, ustream[0], nullptr));
+        DVO_TRY(upload_rows(in_sigma.p, sigma, rb, h, 1, geoD.culls, dec, ustream[0], nullptr));
+        DVO_HIP(hipEventRecord(uevent[0], ustream[0]));
+        build_pyramid(target->fs, nullptr, in_depth.as<float>(), in_sigma.as<float>(), ustream[0], true, dec);
+        DVO_HIP(hipEventRecord(uevent[1], ustream[0]));
+        side_built = true;
+        return DVO_OK;
+    };
+    in.gray = in_gray.as<float>(); in.depth = nullptr; in.sigma = nullptr;
+    const int rc = odometrize_depth_staged(T_rel, &in, &side);
+    if (side_built) DVO_HIP(hipEventSynchronize(uevent[0]));   // (long done: the copies take ~50 us, the tracking ~270)
+    return rc;
 }
 
 int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16])
@@ -962,13 +996,17 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
     FrameInput in;
     in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);   // only the rows the pyramid keeps cross PCIe
+    DVO_TRY(upload_streams());
+    if (side_built) { DVO_HIP(hipStreamWaitEvent(stream, uevent[1], 0)); side_built = false; }   // a float-map frame's depth pyramid may still be building: it is this call's reference
+    DVO_TRY(upload_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, ustream[0], nullptr));
+    DVO_HIP(hipEventRecord(uevent[0], ustream[0]));
     DVO_TRY(upload_rows(raw_rgb.p, rgb, (size_t)w * channels, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
-    DVO_TRY(upload_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));
+    DVO_HIP(hipStreamWaitEvent(stream, uevent[0], 0));
     in.rgb = raw_rgb.as<uint8_t>(); in.channels = channels; in.depth16 = raw_depth.as<uint16_t>(); in.depth_scale = depth_scale;
     return odometrize_depth_staged(T_rel, &in);
 }
 
-int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* raw)
+int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* raw, const std::function<int()>* after_launch)
 {
     if (!trkD_ready) { trkD.prefer_persist = true; DVO_TRY(trkD.init(geoD, 1, cfg)); trkD_ready = true; }
     if (!depth_cur) { depth_cur = std::make_unique<Keyframe>(); DVO_TRY(depth_cur->alloc(geoD, cfg)); }
@@ -979,6 +1017,7 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* r
     const float z[6] = {0, 0, 0, 0, 0, 0};
     if (!depth_ref) {  // system.hpp:83-86
         for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
+        if (after_launch) DVO_TRY((*after_launch)());
         DVO_HIP(hipStreamSynchronize(stream));
         depth_ref = std::move(depth_cur);
         se3_exp_f(z, T_rel);
@@ -986,6 +1025,7 @@ int VisualOdometry::odometrize_depth_staged(float T_rel[16], const FrameInput* r
     }
     DVO_TRY(trkD.enable_host_result());
     DVO_TRY(trkD.track(frame.fs, depth_ref->fs, stream));
+    if (after_launch) DVO_TRY((*after_launch)());   // (work that is not on this frame's critical path is queued once the tracking is)
     // The pose comes back through mapped host memory (k_export_poses' last store), not through a copy + stream synchronisation; the
     // caller's input buffers were consumed by copies that are stream-ordered before the kernels whose result this waits for.
     float rel[6];

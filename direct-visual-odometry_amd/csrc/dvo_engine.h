@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime_api.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -201,8 +202,15 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int odometrize(const float* gray, float T_world[16], int* is_key, const uint8_t* raw = nullptr, int raw_channels = 0);
     int odometrize_depth(const float* gray, const float* depth, const float* sigma, float T_rel[16]);
     int odometrize_depth_raw(const uint8_t* rgb, int channels, const uint16_t* depth16, float depth_scale, float T_rel[16]);
-    int odometrize_depth_staged(float T_rel[16], const struct FrameInput* raw = nullptr);  // frame already staged on the device
+    int odometrize_depth_staged(float T_rel[16], const struct FrameInput* raw = nullptr,   // frame already staged on the device
+                                const std::function<int()>* after_launch = nullptr);
     DevBuf raw_rgb, raw_depth;
+    // the maps of one frame go up on separate streams: three strided copies queued on one stream run one after the other with
+    // ~9 us between them (98 us from the end of one frame's tracking to the next pyramid, profiles/r03_single_hip_trace.txt)
+    hipStream_t ustream[2] = {nullptr, nullptr};
+    hipEvent_t uevent[2] = {nullptr, nullptr};
+    int upload_streams();
+    bool side_built = false;   // uevent[1] marks a depth / sigma pyramid built on the side stream (odometrize_depth)
     bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // as Batch::decimate_host_rows
     int init_keyframe(const float* gray, const float* depth, const float* sigma);
     int map_propagate(Keyframe& frame, const Keyframe& ref);
