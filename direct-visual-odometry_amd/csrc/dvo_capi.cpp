@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -346,6 +347,42 @@ int dvo_batch_synchronize(dvo_batch* b)
     }
     DVO_TRY(select_device(b->impl.device));
     DVO_HIP(hipStreamSynchronize(b->impl.stream));
+    return DVO_OK;
+}
+
+int dvo_shard_range(int n_sequences, int world_size, int rank, int* first, int* count)
+{
+    if (n_sequences < 0 || world_size < 1 || rank < 0 || rank >= world_size || !first || !count) return DVO_ERR_BAD_ARGUMENT;
+    const int base = n_sequences / world_size, extra = n_sequences % world_size;
+    *count = base + (rank < extra ? 1 : 0);
+    *first = rank * base + (rank < extra ? rank : extra);
+    return DVO_OK;
+}
+
+int dvo_batch_gather_poses_rccl(dvo_batch* b, void* rccl_comm, int world_size, float* xi_all_dev)
+{
+    if (!b || !rccl_comm || world_size < 1 || !xi_all_dev) return DVO_ERR_BAD_ARGUMENT;
+    // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclFloat = 7 (rccl.h).  Resolved at run time so that
+    // libdvo.so has no link-time dependency on a collective library it needs on multi-GPU hosts only.
+    typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    static all_gather_fn all_gather = nullptr;
+    if (!all_gather) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h) all_gather = reinterpret_cast<all_gather_fn>(dlsym(h, "ncclAllGather"));
+        if (!all_gather) { set_error("librccl.so (ncclAllGather) could not be loaded"); return DVO_ERR_NOT_READY; }
+    }
+    const float* src; size_t n; hipStream_t st; int dev;
+    if (b->mono) {
+        if (b->mono->latest_id < 0) return DVO_ERR_NOT_READY;
+        src = b->mono->xi_world.as<float>(); n = (size_t)b->mono->n_seq * 6; st = b->mono->stream; dev = b->mono->device;
+    } else {
+        if (!b->impl.have_poses) return DVO_ERR_NOT_READY;
+        src = b->impl.trk.xi_out.as<float>(); n = (size_t)b->impl.n_seq * 6; st = b->impl.stream; dev = b->impl.device;
+    }
+    DVO_TRY(select_device(dev));
+    const int rc = all_gather(src, xi_all_dev, n, 7 /* ncclFloat */, rccl_comm, st);
+    if (rc != 0) { set_error("ncclAllGather failed"); return DVO_ERR_HIP; }
     return DVO_OK;
 }
 

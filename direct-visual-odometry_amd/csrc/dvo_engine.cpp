@@ -394,6 +394,11 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
         if (ppt[l] != ppt[0] || group[l] != group[0] || fused[l] || nblk[l] > 320 || tl.live_count <= 0) persist_ok = false;
         if (tl.live_count > max_tiles) max_tiles = tl.live_count;
     }
+    // ~0.2 s of polling per wait: far beyond any iteration, short enough that a wedged launch ends.  DVO_PERSIST_SPIN_LIMIT (tests): a
+    // limit of 0 makes every launch give up at once, so the fallback path runs; DVO_PERSIST_TIMELINE: in-kernel stamps (diagnostic).
+    persist_spin_limit = 1 << 18;
+    if (const char* e = getenv("DVO_PERSIST_SPIN_LIMIT")) persist_spin_limit = atoi(e);
+    persist_timeline = getenv("DVO_PERSIST_TIMELINE") != nullptr;
     if (persist_ok) {
         int cap = 0;
         if (track_persist_max_grid(ppt[0], group[0], &cap) != DVO_OK || cap < 1) persist_ok = false;
@@ -478,13 +483,12 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         result_tag = (result_tag + 1) & 0x1fffff;
         if (result_tag == 0) result_tag = 1;
         pa.host_tag = result_tag;
-        pa.spin_limit = 1 << 18;   // ~0.2 s of polling: far beyond any iteration, short enough that a wedged launch ends
-        if (getenv("DVO_PERSIST_TIMELINE")) {   // diagnostic: stamps of the solver and of worker 0 (tools/persist_timeline.py reads them back)
+        pa.spin_limit = persist_spin_limit;
+        if (persist_timeline) {   // diagnostic: stamps of the solver and of worker 0 (tools/persist_timeline.py reads them back)
             if (!persist_dbg.p) { DVO_TRY(persist_dbg.alloc(2 * 64 * 8 * sizeof(long long))); }
             DVO_HIP(hipMemsetAsync(persist_dbg.p, 0, persist_dbg.bytes, s));
             pa.dbg = persist_dbg.as<long long>();
         }
-        if (const char* e = getenv("DVO_PERSIST_SPIN_LIMIT")) pa.spin_limit = atoi(e);   // (tests: a limit of 0 makes every launch give up -> the fallback runs)
         if (launch_track_persist(pa, ppt[0], group[0], persist_grid, s)) {
             persist_used = true;
             DVO_HIP(hipGetLastError());

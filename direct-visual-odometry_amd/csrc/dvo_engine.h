@@ -139,7 +139,8 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     // (GPU oversubscribed): the handle then stays on the launch-per-iteration schedule.
     bool prefer_persist = false;   // set before init() by the owner whose results go through enable_host_result() (VisualOdometry's sensor-depth tracker)
     bool persist_ok = false, persist_failed = false, persist_used = false;
-    int persist_grid = 0;
+    int persist_grid = 0, persist_spin_limit = 1 << 18;
+    bool persist_timeline = false;
     DevBuf persist_ctl, persist_dbg;
     int read_persist_timeline(long long* out);
     const FrameSet* last_obj = nullptr; const FrameSet* last_ref = nullptr;

@@ -1149,6 +1149,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
             a.ignore_active = 1; a.list = nullptr; a.next_count = nullptr; a.n_seq = 1;
             a.blk_first = L.blk_first; a.blk_count = L.blk_count; a.t_shift = L.t_shift; a.x_org = L.x_org; a.y_org = L.y_org;
             a.tiles_x = L.tiles_x; a.tiles_y = 0; a.margin = 0;
+            if (stamp) p.dbg[(64 + step) * 8 + 3] = wall_clock64();   // arguments and pose in registers
             for (int t = me; t < L.blk_count; t += n_work) {
                 float* row = p.partials + (size_t)(L.blk_first + t) * 32;
                 if constexpr (PPT == 4) {
@@ -1159,6 +1160,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
                 }
                 __syncthreads();   // (the next tile reuses the LDS scratch)
             }
+            if (stamp) p.dbg[(64 + step) * 8 + 4] = wall_clock64();   // gn_tile returned
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's row stores have left
             __syncthreads();
             if (stamp) p.dbg[(64 + step) * 8 + 1] = wall_clock64();   // tiles done

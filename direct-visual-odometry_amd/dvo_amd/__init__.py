@@ -84,7 +84,7 @@ EXPORTS = [
     "dvo_vo_odometrize_depth", "dvo_vo_odometrize_raw", "dvo_vo_keyframe_count", "dvo_vo_keyframe_info", "dvo_vo_keyframe_get",
     "dvo_vo_last_frame_pose", "dvo_vo_last_valid_updates", "dvo_vo_last_track_log", "dvo_debug_persist_timeline",
     "dvo_batch_create", "dvo_batch_destroy", "dvo_batch_push_device", "dvo_batch_push_host", "dvo_batch_last_poses",
-    "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn",
+    "dvo_batch_prefetch_device", "dvo_batch_copy_poses_device", "dvo_batch_last_track_log", "dvo_batch_synchronize", "dvo_batch_profile", "dvo_batch_probe_gn", "dvo_shard_range", "dvo_batch_gather_poses_rccl",
     "dvo_batch_push_raw_device", "dvo_batch_prefetch_raw_device", "dvo_batch_push_raw_host", "dvo_batch_odometrize_raw_device",
     "dvo_batch_odometrize_host", "dvo_batch_odometrize_raw_host",
     "dvo_batch_create_mono", "dvo_batch_set_initial_depth", "dvo_batch_set_initial_depth_device", "dvo_batch_odometrize_device",

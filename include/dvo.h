@@ -167,6 +167,16 @@ int dvo_batch_last_poses(dvo_batch* b, float* xi_rel, float* T_rel);
 int dvo_batch_copy_poses_device(dvo_batch* b, float* xi_dst_dev, float* T_dst_dev);
 int dvo_batch_last_track_log(dvo_batch* b, int seq, dvo_track_log* log);
 int dvo_batch_synchronize(dvo_batch* b);
+/* ---- one block of sequences per GPU (BASELINE config 5) -------------------------------------------
+ * The path shards across sequences only (frame t of a sequence tracks against state from frames < t: system.hpp:48,57,67): every
+ * rank -- one process per GPU -- owns a contiguous block of the sequences and tracks it with no communication.
+ * dvo_shard_range: the block of `rank` (counts differ by at most one; the split of dvo_amd/shard.py and bench.py --gpus N).
+ * dvo_batch_gather_poses_rccl: the one collective of the path, from C++: an all-gather of the last push's twists over RCCL / xGMI,
+ * queued on the handle's stream.  `rccl_comm` is the caller's ncclComm_t (ncclCommInitRank over its own bootstrap -- MPI,
+ * torch.distributed's store, a shared file); every rank must hold the same n_seq (pad the last block).  xi_all_dev: device memory
+ * [world_size][n_seq][6].  librccl.so is loaded on first use (dlopen): DVO_ERR_NOT_READY with an explanation when it is absent. */
+int dvo_shard_range(int n_sequences, int world_size, int rank, int* first, int* count);
+int dvo_batch_gather_poses_rccl(dvo_batch* b, void* rccl_comm, int world_size, float* xi_all_dev);
 /* Profile counters (cfg.profile = 1): accumulated over every k_track_gn launch since the last reset. */
 typedef struct dvo_gn_profile {
     double   gn_ms;             /* sum of hipEvent-bracketed k_track_gn durations                         */

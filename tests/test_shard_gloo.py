@@ -77,3 +77,22 @@ def test_gather_poses_world_size_2():
             for f in range(n):
                 assert poses[s, f, 0] == s and poses[s, f, 1] == f and poses[s, f, 5] == r
             assert not poses[s, n:].any()
+
+
+def test_c_abi_shard_range_equals_the_python_split():
+    """dvo_shard_range (include/dvo.h): the block of sequences a rank owns, for a C++ host -- the same split as shard.assign_sequences."""
+    import ctypes as C
+    import dvo_amd as dvo
+    from dvo_amd import shard
+    L = dvo.lib()
+    for n in (0, 1, 7, 8, 9, 16384, 100003):
+        for world in (1, 2, 3, 4, 8):
+            want = shard.assign_sequences(n, world)
+            for r in range(world):
+                first, count = C.c_int(), C.c_int()
+                assert L.dvo_shard_range(n, world, r, C.byref(first), C.byref(count)) == 0
+                assert (first.value, count.value) == want[r], (n, world, r)
+    f, c = C.c_int(), C.c_int()
+    assert L.dvo_shard_range(8, 0, 0, C.byref(f), C.byref(c)) == dvo.DVO_ERR_BAD_ARGUMENT
+    assert L.dvo_shard_range(8, 2, 2, C.byref(f), C.byref(c)) == dvo.DVO_ERR_BAD_ARGUMENT
+    assert L.dvo_batch_gather_poses_rccl(None, None, 1, None) == dvo.DVO_ERR_BAD_ARGUMENT
