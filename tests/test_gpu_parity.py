@@ -716,3 +716,33 @@ def test_single_handle_schedules_give_the_same_bits(monkeypatch):
                     np.testing.assert_array_equal(a["xi_update"][l], b["xi_update"][l])
                     np.testing.assert_array_equal(a["n_valid"][l], b["n_valid"][l])
                     np.testing.assert_array_equal(a["residual"][l], b["residual"][l])
+
+
+def test_single_handle_one_launch_schedule_edge_cases():
+    """k_track_persist (one launch per odometrizeUsingDepth call) where its control flow is unusual: a fixed iteration count (the
+    level never 'stops' by a threshold), a reference without any usable depth (every step has zero contributing pixels: residual -1,
+    zero update, optimize.cpp:92-93 -> each level leaves after one iteration and the pose stays the identity), and a reference whose
+    depth makes every pixel project outside the image.  Each against the launch-pair schedule, bit for bit; nothing may hang."""
+    g, d, s, _ = frames(4, seed=42, sigma=0.1)
+    cases = {
+        "fixed_iterations": (dict(fixed_iterations=3, crop_enable=0), [(g[i], d[i], s[i]) for i in range(3)]),
+        "no_depth": (dict(), [(g[0], np.zeros_like(d[0]), s[0]), (g[1], np.zeros_like(d[1]), s[1]), (g[2], d[2], s[2]), (g[3], d[3], s[3])]),
+        "far_outside": (dict(), [(g[0], np.full_like(d[0], 1e-3 + 0.2), s[0]), (g[1], d[1], s[1]), (g[2], d[2], s[2])]),
+    }
+    for name, (kw, seq) in cases.items():
+        res = {}
+        for sched in (0, -1):
+            vo = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(track_single_launch=sched, gn_pixels_per_thread=4, **kw))
+            out = []
+            for (gg, dd, ss) in seq:
+                T = vo.odometrizeUsingDepth(gg, dd, ss)
+                out.append((T.copy(), vo.lastTrackLog()["n_iter"] if len(out) else None))
+            vo.close()
+            res[sched] = out
+        for i in range(len(seq)):
+            np.testing.assert_array_equal(res[0][i][0].view(np.uint32), res[-1][i][0].view(np.uint32), err_msg="%s frame %d" % (name, i))
+            assert res[0][i][1] == res[-1][i][1], (name, i)
+        if name == "fixed_iterations":
+            assert res[0][2][1] == [3, 3, 3, 3]
+        if name == "no_depth":
+            assert res[0][1][1] == [1, 1, 1, 1] and np.array_equal(res[0][1][0], np.eye(4, dtype=np.float32))
