@@ -9,6 +9,8 @@
       INVALID bit mask (a 640 x 480 frame that decimates to exactly this level is rebuilt by pixel repetition).
       Expected outputs = the CPU oracle's VisualOdometry::odometrize over those frames (keyframe flags, world poses, age
       maps, keyframe depth maps).  ORACLE-DERIVED: parity unpinned (the reference cannot be built here).
+  kinect50mm_ir_depth.npz, kinect1deg_ir_depth.npz  four registered (IR, depth) pairs of data/KINECT_50MM (translation, ~50 mm per
+      frame) and data/KINECT_1DEG (rotation, ~1 degree per frame), decimated by 2: inputs only.
   kinect50mm_excerpt.npz  one data/KINECT_50MM depth PNG (u16, 512 x 424) decimated by 2 and the matching rgb PNG sampled
       to the same size: inputs only; the expected k_ingest outputs are integer arithmetic restated in numpy by the test.
 
@@ -74,14 +76,17 @@ def main():
 
     # ---- KINECT_50MM as a sensor-depth sequence: the IR image is registered with the depth image (same sensor), so four
     #      (ir, depth) pairs are a real RGB-D-like input with real holes and noise for the odometrizeUsingDepth path ----
-    irs, deps = [], []
-    for k in (1, 2, 3, 4):
-        ir = dvo.imread(os.path.join(REF, "KINECT_50MM", "ir%02d.png" % k))      # [424, 512] u16
-        dd = dvo.imread(os.path.join(REF, "KINECT_50MM", "depth%02d.png" % k))
-        irs.append(np.minimum(ir[::2, ::2] >> 5, 255).astype(np.uint8))           # 256 x 212 u8 gray
-        deps.append(dd[::2, ::2].copy())
-    np.savez_compressed(os.path.join(HERE, "kinect50mm_ir_depth.npz"), gray_u8=np.stack(irs), depth16=np.stack(deps))
-    print("kinect ir/depth sequence:", np.stack(irs).shape, "holes %.3f" % (np.stack(deps) == 0).mean())
+    #      KINECT_1DEG is the same sensor turning ~1 degree per frame: the rotation-dominant counterpart (the reference's README: rotation
+    #      tracking "did not work well") ----
+    for name, out in (("KINECT_50MM", "kinect50mm_ir_depth.npz"), ("KINECT_1DEG", "kinect1deg_ir_depth.npz")):
+        irs, deps = [], []
+        for k in (1, 2, 3, 4):
+            ir = dvo.imread(os.path.join(REF, name, "ir%02d.png" % k))      # [424, 512] u16
+            dd = dvo.imread(os.path.join(REF, name, "depth%02d.png" % k))
+            irs.append(np.minimum(ir[::2, ::2] >> 5, 255).astype(np.uint8))           # 256 x 212 u8 gray
+            deps.append(dd[::2, ::2].copy())
+        np.savez_compressed(os.path.join(HERE, out), gray_u8=np.stack(irs), depth16=np.stack(deps))
+        print(name, "ir/depth sequence:", np.stack(irs).shape, "holes %.3f" % (np.stack(deps) == 0).mean())
 
 
 if __name__ == "__main__":

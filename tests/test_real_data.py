@@ -223,18 +223,22 @@ def test_undistort_kernel_on_a_real_frame():
 K_KINECT_IR = np.array([[365.0, 0, 256.0], [0, 365.0, 212.0], [0, 0, 1]], np.float32)   # nominal Kinect v2 depth / IR intrinsics (512 x 424)
 
 
-def _kinect_sequence():
-    """Four (IR, depth) pairs of data/KINECT_50MM as raw sensor frames at 512 x 424 (the stored 256 x 212 excerpt, every pixel
-    repeated 2 x 2, decimates back to exactly the stored pixels in Frame(g, d, s, K, 4, 1)) and as the float maps the loader makes."""
-    fx = np.load(os.path.join(GOLD, "kinect50mm_ir_depth.npz"))
+KINECT_SETS = ["kinect50mm_ir_depth.npz", "kinect1deg_ir_depth.npz"]   # ~50 mm translation per frame; ~1 degree rotation per frame
+
+
+def _kinect_sequence(name="kinect50mm_ir_depth.npz"):
+    """Four (IR, depth) pairs of data/KINECT_50MM (or KINECT_1DEG) as raw sensor frames at 512 x 424 (the stored 256 x 212 excerpt, every
+    pixel repeated 2 x 2, decimates back to exactly the stored pixels in Frame(g, d, s, K, 4, 1)) and as the float maps the loader makes."""
+    fx = np.load(os.path.join(GOLD, name))
     g8 = np.repeat(np.repeat(fx["gray_u8"], 2, axis=1), 2, axis=2)
     d16 = np.repeat(np.repeat(fx["depth16"], 2, axis=1), 2, axis=2)
     fl = [ingest_np(g8[i], d16[i]) for i in range(g8.shape[0])]
     return g8, d16, fl
 
 
-def test_kinect_sequence_fixture_has_real_holes():
-    g8, d16, fl = _kinect_sequence()
+@pytest.mark.parametrize("name", KINECT_SETS)
+def test_kinect_sequence_fixture_has_real_holes(name):
+    g8, d16, fl = _kinect_sequence(name)
     assert g8.shape == (4, 424, 512) and 0.03 < (d16 == 0).mean() < 0.2
     g, d, s = fl[0]
     assert (g[d16[0] == 0] == -2.0).all() and (s[d16[0] == 0] == 1.0).all() and (s[d16[0] > 0] == np.float32(0.1)).all()
@@ -245,14 +249,15 @@ def test_kinect_sequence_fixture_has_real_holes():
 
 
 @pytest.mark.gpu
-def test_sensor_depth_tracking_on_kinect_frames_matches_the_oracle_at_every_iteration():
+@pytest.mark.parametrize("name", KINECT_SETS)
+def test_sensor_depth_tracking_on_kinect_frames_matches_the_oracle_at_every_iteration(name):
     """Tracker::track (tracker.cpp:22-85) as odometrizeUsingDepth runs it (Frame(g,d,s,K,4,1), sigma 0.1 / 1.0, INVALID gray in the
     depth holes: transform.cpp:60-76) on real Kinect IR + depth frames with 6 % holes.  Along the GPU's own trajectory every
     iteration is checked against the oracle at the same input pose: contributing-pixel count exact, residual 1e-4, and the
     update solves the oracle's normal equations to a backward error <= 2e-6 (also where the diverged pose leaves a handful of pixels and a singular system); first-iteration masks bit-exact on every level;
     the raw (u8 + u16) entry point equals the float one bit for bit."""
     import dvo_amd as dvo
-    g8, d16, fl = _kinect_sequence()
+    g8, d16, fl = _kinect_sequence(name)
     cfg = dvo.default_config(gn_pixels_per_thread=4)
     vo_raw = dvo.VisualOdometry(K_KINECT_IR, 512, 424, cfg=cfg)
     vo_flt = dvo.VisualOdometry(K_KINECT_IR, 512, 424, cfg=cfg)
