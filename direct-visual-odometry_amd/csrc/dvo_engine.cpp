@@ -929,11 +929,9 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     launch_mono_decide(meta_dev.as<MonoSeq>(), trkM.state.as<SeqState>(), 1, frame.id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
                        nullptr, nullptr, nullptr, &hdr, stream);
     DVO_HIP(hipMemcpyAsync(h_pin, meta_dev.p, sizeof(MonoSeq), hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipMemcpyAsync(reinterpret_cast<char*>(h_pin) + sizeof(MonoSeq), trkM.log.p, sizeof last_log, hipMemcpyDeviceToHost, stream));
     DVO_HIP(hipStreamSynchronize(stream));
     memcpy(&h_meta, h_pin, sizeof h_meta);
-    memcpy(&last_log, reinterpret_cast<char*>(h_pin) + sizeof(MonoSeq), sizeof last_log);
-    log_src = nullptr;
+    log_src = &trkM;   // (the 15 KB per-iteration log is read back when dvo_vo_last_track_log asks for it)
     memcpy(frame.rel_xi, h_meta.rel_xi, sizeof frame.rel_xi);
     memcpy(frame.xi, h_meta.frame_xi, sizeof frame.xi);
     frame.ref_id = ref.id;
