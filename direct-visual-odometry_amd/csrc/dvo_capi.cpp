@@ -183,7 +183,12 @@ int dvo_debug_persist_timeline(dvo_vo* vo, long long* out)
     return vo->impl.trkD.read_persist_timeline(out);
 }
 
-int dvo_vo_last_valid_updates(const dvo_vo* vo) { return vo ? vo->impl.last_valid_updates : 0; }
+int dvo_vo_last_valid_updates(const dvo_vo* vo)
+{
+    if (!vo) return 0;
+    (void)const_cast<dvo_vo*>(vo)->impl.fetch_valid_updates();   // (read back on demand)
+    return vo->impl.last_valid_updates;
+}
 
 int dvo_vo_last_track_log(const dvo_vo* vo, dvo_track_log* log)
 {

@@ -723,6 +723,16 @@ int Keyframe::alloc(const Geometry& g, const dvo_config& cfg)
 }
 
 // ------------------------------------------------------------------------------------------------ VisualOdometry
+int VisualOdometry::fetch_valid_updates()
+{
+    if (!valid_updates_pending) return DVO_OK;
+    DVO_TRY(select_device(device));
+    DVO_HIP(hipMemcpyAsync(&last_valid_updates, valid_dev.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DVO_HIP(hipStreamSynchronize(stream));
+    valid_updates_pending = false;
+    return DVO_OK;
+}
+
 int VisualOdometry::fetch_log()
 {
     if (!log_src) return DVO_OK;
@@ -808,6 +818,7 @@ int VisualOdometry::init_keyframe(const float* gray, const float* depth, const f
     DVO_HIP(hipMemsetAsync(kf->age.p, 0, kf->age.bytes, stream));
     DVO_HIP(hipStreamSynchronize(stream));
     hist.push_back(std::move(kf));
+    hist_version++;
     return DVO_OK;
 }
 
@@ -831,20 +842,27 @@ int VisualOdometry::map_update(Keyframe& obj)
     Keyframe& ref = *hist.back();
     const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
     const int n_hist = (int)hist.size();
-    // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe, on the device (k_age_table)
-    std::vector<float> hx((size_t)n_hist * 6);
-    std::vector<const float*> gt((size_t)n_hist);
-    for (int i = 0; i < n_hist; i++) {
-        memcpy(&hx[(size_t)i * 6], hist[i]->xi, 6 * sizeof(float));
-        gt[i] = hist[i]->fs.gray[T];
+    // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe, on the device (k_age_table).  The keyframes' poses and
+    // top-level gray pointers only change when FrameHistory does (a keyframe pushed, dropped or loaded): the device copies are
+    // refreshed then (hist_version), not on every frame -- two uploads and a stream synchronisation less per tracked frame.
+    if (hist_table_version != hist_version || hist_table_n != n_hist) {
+        hist_hx.resize((size_t)n_hist * 6);
+        hist_gt.resize((size_t)n_hist);
+        for (int i = 0; i < n_hist; i++) {
+            memcpy(&hist_hx[(size_t)i * 6], hist[i]->xi, 6 * sizeof(float));
+            hist_gt[i] = hist[i]->fs.gray[T];
+        }
+        if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) {
+            DVO_HIP(hipStreamSynchronize(stream));   // (the old tables may still be read by queued kernels)
+            DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
+            DVO_TRY(hist_xi_dev.alloc(sizeof(float) * 6 * (size_t)n_hist * 2));
+            DVO_TRY(gray_tab_dev.alloc(sizeof(float*) * (size_t)n_hist * 2));
+        }
+        DVO_HIP(hipMemcpyAsync(hist_xi_dev.p, hist_hx.data(), hist_hx.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        DVO_HIP(hipMemcpyAsync(gray_tab_dev.p, hist_gt.data(), hist_gt.size() * sizeof(float*), hipMemcpyHostToDevice, stream));
+        DVO_HIP(hipStreamSynchronize(stream));       // hist_hx / hist_gt are pageable host memory: done before they can change again
+        hist_table_n = n_hist; hist_table_version = hist_version;
     }
-    if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) {
-        DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
-        DVO_TRY(hist_xi_dev.alloc(sizeof(float) * 6 * (size_t)n_hist * 2));
-        DVO_TRY(gray_tab_dev.alloc(sizeof(float*) * (size_t)n_hist * 2));
-    }
-    DVO_HIP(hipMemcpyAsync(hist_xi_dev.p, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    DVO_HIP(hipMemcpyAsync(gray_tab_dev.p, gt.data(), gt.size() * sizeof(float*), hipMemcpyHostToDevice, stream));
     AgeTableArgs ta;
     ta.meta = meta_dev.as<MonoSeq>(); ta.hist_xi = hist_xi_dev.as<float>(); ta.ages = ages.as<AgeEntry>();
     ta.n_seq = 1; ta.R = n_hist; ta.n_hist = n_hist;
@@ -864,9 +882,9 @@ int VisualOdometry::map_update(Keyframe& obj)
     memcpy(a.K9, geoM.K9[T], sizeof a.K9);
     a.valid_updates = nullptr;
     launch_depth_update(a, stream);
-    DVO_HIP(hipMemcpyAsync(&last_valid_updates, reinterpret_cast<char*>(meta_dev.p) + offsetof(MonoSeq, valid_updates), sizeof(int),
-                           hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipStreamSynchronize(stream));  // hx / gt are pageable host memory: keep them alive until the copies are done
+    // mapper.cpp:136's count: parked in valid_dev (the next frame's k_mono_decide resets the MonoSeq field) until dvo_vo_last_valid_updates asks
+    DVO_HIP(hipMemcpyAsync(valid_dev.p, reinterpret_cast<char*>(meta_dev.p) + offsetof(MonoSeq, valid_updates), sizeof(int), hipMemcpyDeviceToDevice, stream));
+    valid_updates_pending = true;
     redecimate(ref.fs, ref.fs.depth[T], ref.fs.sigma[T], stream);  // mapper.cpp:135
     return DVO_OK;
 }
@@ -914,6 +932,7 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
         redecimate(frame.fs, frame.fs.depth[T], frame.fs.sigma[T], stream);
         DVO_HIP(hipStreamSynchronize(stream));
         hist.push_back(std::move(scratch));
+        hist_version++;
         const float z[6] = {0, 0, 0, 0, 0, 0};
         se3_exp_f(z, T_world);
         if (is_key) *is_key = 1;
@@ -943,10 +962,12 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     if (need) {
         DVO_TRY(map_propagate(frame, ref));
         hist.push_back(std::move(scratch));
+        hist_version++;
         if (is_key) *is_key = 1;
         if (history_limit > 0 && (int)hist.size() > history_limit) {  // bounded store: drop the oldest keyframes
             DVO_HIP(hipStreamSynchronize(stream));                    // their buffers may still be read by queued kernels
             hist.erase(hist.begin(), hist.begin() + ((int)hist.size() - history_limit));
+            hist_version++;
         }
     } else {
         DVO_TRY(map_update(frame));

@@ -194,6 +194,12 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int latest_id = -1;                                // Frame::latest_id, frame.cpp:5
     int history_limit = 0;                             // 0 = keep every keyframe (the reference); N = keep the newest N
     int last_id = -1, last_valid_updates = 0;
+    bool valid_updates_pending = false;                // last_valid_updates is stale: the count of the last map_update is still on the device
+    int fetch_valid_updates();
+    // device copies of FrameHistory's poses / gray pointers (k_age_table, k_depth_update): refreshed when the history changes
+    std::vector<float> hist_hx; std::vector<const float*> hist_gt;
+    int hist_table_n = -1;
+    unsigned long long hist_version = 0, hist_table_version = ~0ull;   // hist_version: bumped wherever `hist` changes
     float last_xi[6] = {0}, last_rel[6] = {0};
     dvo_track_log last_log;
     Tracker* log_src = nullptr;                        // the tracker whose device log is newer than last_log (read back on demand only)

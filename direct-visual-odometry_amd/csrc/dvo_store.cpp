@@ -119,6 +119,7 @@ int dvo_vo_load(dvo_vo* vo, const char* path)
     if (!ok) { set_error("truncated keyframe store"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_HIP(hipStreamSynchronize(v.stream));
     v.hist = std::move(hist);
+    v.hist_version++;   // (the device copies of the history's poses / gray pointers are rebuilt by the next map_update)
     v.latest_id = h.latest_id;
     return DVO_OK;
 }
