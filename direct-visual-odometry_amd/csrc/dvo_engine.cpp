@@ -91,9 +91,26 @@ int DevBuf::alloc(size_t n)
 }
 void DevBuf::release()
 {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+}
+
+int KeyframePool::take(size_t bytes, void** out)
+{
+    if (block_bytes == 0) block_bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > block_bytes) { set_error("keyframe pool: block size changed"); return DVO_ERR_BAD_ARGUMENT; }
+    if (free_blocks.empty()) {
+        const int per_slab = 16;
+        auto slab = std::make_unique<DevBuf>();
+        DVO_TRY(slab->alloc(block_bytes * per_slab));
+        for (int i = per_slab - 1; i >= 0; i--) free_blocks.push_back(static_cast<char*>(slab->p) + block_bytes * (size_t)i);
+        slabs.push_back(std::move(slab));
+    }
+    *out = free_blocks.back();
+    free_blocks.pop_back();
+    return DVO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ geometry
@@ -144,11 +161,12 @@ static float level_step(const dvo_config& c, int level)
     return c.step_default;
 }
 
-int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg)
+int FrameSet::alloc(const Geometry& geo, int n, const dvo_config& cfg, void* mem)
 {
     g = geo;
     n_seq = n;
-    DVO_TRY(arena.alloc(4 * g.px_total * (size_t)n * sizeof(float)));
+    if (mem) arena.adopt(mem, arena_bytes(g, n));
+    else DVO_TRY(arena.alloc(arena_bytes(g, n)));
     float* p = arena.as<float>();
     for (int m = 0; m < 4; m++)
         for (int l = 0; l < g.levels; l++) {
@@ -333,7 +351,10 @@ int Tracker::init(const Geometry& geo, int n, const dvo_config& c)
             if (fused[l]) p = 4;
             // (one sequence on the one-launch-per-call schedule keeps 4 pixels per thread: k_track_persist's workgroups wait for each
             //  other, and 75 of them hand over faster than 300 -- 406 against 451 us per 640x480 frame, profiles/r03_single_ab.txt)
-            const bool single_p4 = prefer_persist && n_seq == 1 && cfg.track_single_launch == 0 && !cfg.profile;
+            //  A mono handle's levels (at most 160 x 120) show no such difference -- 132-140 us per frame at 1, 2 and 4 pixels per
+            //  thread -- so it keeps the tile size every other schedule picks for one sequence (persist_ppt < 0): the same bits.)
+            const bool single_p4 = prefer_persist && n_seq == 1 && cfg.track_single_launch == 0 && !cfg.profile && persist_ppt >= 0;
+            if (single_p4 && auto_p && persist_ppt > 0) p = persist_ppt;
             while (!fused[l] && auto_p && !single_p4 && p > 1 && (size_t)n_seq * gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l) < 1024) p >>= 1;
             nblk[l] = gn_blocks_per_seq(g.w[l], g.h[l], p, crop_l);
             tiles_x[l] = tiles_y[l] = 0;
@@ -484,6 +505,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
         if (result_tag == 0) result_tag = 1;
         pa.host_tag = result_tag;
         pa.spin_limit = persist_spin_limit;
+        pa.mono = mono_tail;
         if (persist_timeline) {   // diagnostic: stamps of the solver and of worker 0 (tools/persist_timeline.py reads them back)
             if (!persist_dbg.p) { DVO_TRY(persist_dbg.alloc(2 * 64 * 8 * sizeof(long long))); }
             DVO_HIP(hipMemsetAsync(persist_dbg.p, 0, persist_dbg.bytes, s));
@@ -660,8 +682,8 @@ int Tracker::read_persist_timeline(long long* out)   // [2][64][8]
 int Tracker::enable_host_result()
 {
     if (h_result) return DVO_OK;
-    DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_result), 32 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(h_result, 0, 32 * sizeof(float));
+    DVO_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_result), 64 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_result, 0, 64 * sizeof(float));
     DVO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_result), h_result, 0));
     return DVO_OK;
 }
@@ -715,10 +737,23 @@ int Tracker::collect_profile(hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------ keyframes
-int Keyframe::alloc(const Geometry& g, const dvo_config& cfg)
+int Keyframe::alloc(const Geometry& g, const dvo_config& cfg, KeyframePool* from)
 {
-    DVO_TRY(fs.alloc(g, 1, cfg));
-    DVO_TRY(age.alloc(sizeof(float) * (size_t)g.w[g.top()] * g.h[g.top()]));
+    const size_t top = sizeof(float) * (size_t)g.w[g.top()] * g.h[g.top()];
+    if (from) {   // one block of the pool: [arena | age | depth_alt], each 256-byte aligned
+        const size_t a0 = (FrameSet::arena_bytes(g, 1) + 255) & ~(size_t)255, a1 = (top + 255) & ~(size_t)255;
+        void* blk = nullptr;
+        DVO_TRY(from->take(a0 + 2 * a1, &blk));
+        pool = from; block = blk;
+        DVO_TRY(fs.alloc(g, 1, cfg, blk));
+        age.adopt(static_cast<char*>(blk) + a0, top);
+        depth_alt.adopt(static_cast<char*>(blk) + a0 + a1, top);
+    } else {
+        DVO_TRY(fs.alloc(g, 1, cfg));
+        DVO_TRY(age.alloc(top));
+        DVO_TRY(depth_alt.alloc(top));
+    }
+    depth_spare = depth_alt.as<float>();
     return DVO_OK;
 }
 
@@ -746,10 +781,8 @@ int VisualOdometry::fetch_log()
 int VisualOdometry::upload_streams()
 {
     if (ustream[0]) return DVO_OK;
-    for (int i = 0; i < 2; i++) {
-        DVO_HIP(hipStreamCreateWithFlags(&ustream[i], hipStreamNonBlocking));
-        DVO_HIP(hipEventCreateWithFlags(&uevent[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < 2; i++) DVO_HIP(hipStreamCreateWithFlags(&ustream[i], hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) DVO_HIP(hipEventCreateWithFlags(&uevent[i], hipEventDisableTiming));   // [2]: the mono frame's upload
     return DVO_OK;
 }
 
@@ -757,8 +790,9 @@ VisualOdometry::~VisualOdometry()
 {
     for (int i = 0; i < 2; i++) {
         if (ustream[i]) { (void)hipStreamSynchronize(ustream[i]); (void)hipStreamDestroy(ustream[i]); }
-        if (uevent[i]) (void)hipEventDestroy(uevent[i]);
     }
+    for (int i = 0; i < 3; i++)
+        if (uevent[i]) (void)hipEventDestroy(uevent[i]);
     if (h_pin) (void)hipHostFree(h_pin);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -812,7 +846,7 @@ int VisualOdometry::init_keyframe(const float* gray, const float* depth, const f
     DVO_HIP(hipMemcpyAsync(in_depth.p, depth, n, hipMemcpyHostToDevice, stream));
     DVO_HIP(hipMemcpyAsync(in_sigma.p, sigma, n, hipMemcpyHostToDevice, stream));
     auto kf = std::make_unique<Keyframe>();
-    DVO_TRY(kf->alloc(geoM, cfg));
+    DVO_TRY(kf->alloc(geoM, cfg, &kf_pool));
     kf->id = ++latest_id;
     build_pyramid(kf->fs, in_gray.as<float>(), in_depth.as<float>(), in_sigma.as<float>(), stream);
     DVO_HIP(hipMemsetAsync(kf->age.p, 0, kf->age.bytes, stream));
@@ -833,7 +867,8 @@ int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
     a.meta = meta_dev.as<MonoSeq>();
     memset(&a.pose, 0, sizeof a.pose); a.tz = 0.0f;
     launch_propagate_batch(a, stream);
-    redecimate(frame.fs, frame.fs.depth[T], frame.fs.sigma[T], stream);  // Frame::updateDepthSigmaAge, frame.cpp:47-54
+    // (Frame::updateDepthSigmaAge, frame.cpp:47-54, re-decimates both maps here; Mapper::regularize and Frame::updateDepth follow at
+    //  once, mapper.cpp:26, and decimate the depth again: map_regularize() derives every level of both pyramids in its one pass)
     return DVO_OK;
 }
 
@@ -866,6 +901,7 @@ int VisualOdometry::map_update(Keyframe& obj)
     AgeTableArgs ta;
     ta.meta = meta_dev.as<MonoSeq>(); ta.hist_xi = hist_xi_dev.as<float>(); ta.ages = ages.as<AgeEntry>();
     ta.n_seq = 1; ta.R = n_hist; ta.n_hist = n_hist;
+    ta.zero_word = valid_dev.as<int>();   // mapper.cpp:136's count of this update (read back when dvo_vo_last_valid_updates asks)
     launch_age_table(ta, stream);
     UpdateArgs a;
     memset(&a, 0, sizeof a);
@@ -880,21 +916,31 @@ int VisualOdometry::map_update(Keyframe& obj)
     a.seed = cfg.rng_seed;
     a.k = geoM.k[T];
     memcpy(a.K9, geoM.K9[T], sizeof a.K9);
-    a.valid_updates = nullptr;
+    a.valid_updates = valid_dev.as<int>();
     launch_depth_update(a, stream);
-    // mapper.cpp:136's count: parked in valid_dev (the next frame's k_mono_decide resets the MonoSeq field) until dvo_vo_last_valid_updates asks
-    DVO_HIP(hipMemcpyAsync(valid_dev.p, reinterpret_cast<char*>(meta_dev.p) + offsetof(MonoSeq, valid_updates), sizeof(int), hipMemcpyDeviceToDevice, stream));
     valid_updates_pending = true;
-    redecimate(ref.fs, ref.fs.depth[T], ref.fs.sigma[T], stream);  // mapper.cpp:135
+    // (mapper.cpp:135's Frame::updateDepthSigma: folded into map_regularize(), as in map_propagate())
     return DVO_OK;
 }
 
 int VisualOdometry::map_regularize(Keyframe& kf)
-{  // Mapper::regularize, mapper.cpp:139-144
-    const int T = geoM.top(), tw = geoM.w[T], th = geoM.h[T];
-    launch_regularize(kf.fs.depth[T], kf.fs.sigma[T], tw, th, tmp_a.as<float>(), stream);
-    DVO_HIP(hipMemcpyAsync(kf.fs.depth[T], tmp_a.p, sizeof(float) * (size_t)tw * th, hipMemcpyDeviceToDevice, stream));
-    redecimate(kf.fs, kf.fs.depth[T], nullptr, stream);  // Frame::updateDepth, frame.cpp:56-61
+{  // Mapper::regularize (mapper.cpp:139-144) + Frame::updateDepth (frame.cpp:56-61), together with the re-decimation of sigma that the
+   // preceding propagate / update left pending (frame.cpp:39-54): every level of depth and sigma is a decimation of the top maps, so one
+   // pass (k_regularize_redecimate, the batched pipeline's kernel) leaves the values the reference's three re-decimations leave
+    const int T = geoM.top();
+    RegDecArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.depth = kf.fs.depth[T]; ra.sigma = kf.fs.sigma[T];
+    ra.depth_top_out = kf.depth_spare;
+    for (int l = 0; l < geoM.levels; l++) {
+        ra.w[l] = geoM.w[l]; ra.h[l] = geoM.h[l];
+        ra.depth_lv[l] = kf.fs.depth[l]; ra.sigma_lv[l] = kf.fs.sigma[l]; ra.wgt[l] = kf.fs.wgt[l];
+        ra.step[l] = kf.fs.step[l];
+    }
+    ra.levels = geoM.levels; ra.n_seq = 1; ra.sigma_min = kf.fs.sigma_min; ra.sigma_max = kf.fs.sigma_max;
+    kf.fs.sigma_by_validity = false;
+    launch_regularize_redecimate(ra, stream);
+    std::swap(kf.fs.depth[T], kf.depth_spare);   // the top-level depth map alternates between the arena block and depth_alt
     return DVO_OK;
 }
 
@@ -903,20 +949,39 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     if ((!gray && !raw) || !T_world) { set_error("null argument"); return DVO_ERR_BAD_ARGUMENT; }
     if (raw && raw_channels != 1 && raw_channels != 3 && raw_channels != 4) { set_error("bad channel count"); return DVO_ERR_BAD_ARGUMENT; }
     DVO_TRY(select_device(device));
-    if (!trkM_ready) { DVO_TRY(trkM.init(geoM, 1, cfg)); trkM_ready = true; }
+    if (!trkM_ready) {   // one launch per track() call (k_track_persist), as the sensor-depth tracker
+        trkM.prefer_persist = true;
+        if (const char* e = getenv("DVO_MONO_PERSIST")) trkM.prefer_persist = atoi(e) != 0;
+        trkM.persist_ppt = -1;   // the tile size of the other schedules
+        if (const char* e = getenv("DVO_MONO_PERSIST_PPT")) trkM.persist_ppt = atoi(e);
+        DVO_TRY(trkM.init(geoM, 1, cfg));
+        if (trkM.persist_ok) DVO_TRY(trkM.enable_host_result());
+        trkM_ready = true;
+    }
+    // The frame goes up on a stream of its own: the previous call returned with its mapping kernels (update / propagate, regularize)
+    // still queued on `stream`, and a copy queued behind them would wait for them although it touches nothing they do -- the staging
+    // buffers were last read by the previous frame's pyramid, which that call waited for (the pose read-back).  The pyramid waits
+    // for the copy (event), then everything is in stream order again.
+    DVO_TRY(upload_streams());
+    hipStream_t up = ustream[1];
     FrameInput fin;
     if (raw) {
         const size_t px = (size_t)w * h;
-        if (raw_rgb.bytes < px * 4) { DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2)); }
+        if (raw_rgb.bytes < px * 4) {
+            DVO_HIP(hipStreamSynchronize(stream));
+            DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2));
+        }
         fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps cross PCIe
-        DVO_TRY(upload_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
+        DVO_TRY(upload_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
         fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
     } else {
         fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);
-        DVO_TRY(upload_rows(in_gray.p, gray, (size_t)w * sizeof(float), h, 1, geoM.culls, fin.rows_decimated, stream, nullptr));
+        DVO_TRY(upload_rows(in_gray.p, gray, (size_t)w * sizeof(float), h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
         fin.gray = in_gray.as<float>();
     }
-    if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg)); }
+    DVO_HIP(hipEventRecord(uevent[2], up));
+    DVO_HIP(hipStreamWaitEvent(stream, uevent[2], 0));
+    if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg, &kf_pool)); }
     Keyframe& frame = *scratch;
     frame.id = ++latest_id;
     for (int i = 0; i < 6; i++) { frame.xi[i] = 0; frame.rel_xi[i] = 0; }
@@ -939,17 +1004,42 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
         return DVO_OK;
     }
     Keyframe& ref = *hist.back();
-    DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
-    // Frame::updateXi (frame.cpp:7-14), Mapper::needNewFrame (mapper.cpp:45-60) and exp(xi) (system.hpp:73) on the device, by the
-    // kernel the batched pipeline uses; the host keeps FrameHistory, so the reference keyframe's pose and id go up first.
+    // Frame::updateXi (frame.cpp:7-14), Mapper::needNewFrame (mapper.cpp:45-60) and exp(xi) (system.hpp:73) on the device; the host keeps
+    // FrameHistory, so the reference keyframe's pose and id go along as kernel arguments.  On the one-launch schedule they are the tail
+    // of k_track_persist and everything the host needs arrives in the mapped block with the tracker's tag: no further launch, no copy,
+    // no stream synchronisation.  Otherwise: k_mono_decide (the batched pipeline's kernel) + one copy.
     MonoRef hdr;
     memcpy(hdr.ref_xi, ref.xi, sizeof hdr.ref_xi);
     hdr.ref_id = ref.id; hdr.n_total = (int)hist.size(); hdr.valid = 1;
-    launch_mono_decide(meta_dev.as<MonoSeq>(), trkM.state.as<SeqState>(), 1, frame.id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
-                       nullptr, nullptr, nullptr, &hdr, stream);
-    DVO_HIP(hipMemcpyAsync(h_pin, meta_dev.p, sizeof(MonoSeq), hipMemcpyDeviceToHost, stream));
-    DVO_HIP(hipStreamSynchronize(stream));
-    memcpy(&h_meta, h_pin, sizeof h_meta);
+    memset(&trkM.mono_tail, 0, sizeof trkM.mono_tail);
+    if (trkM.persist_ok && !trkM.persist_failed) {
+        PersistMono& pm = trkM.mono_tail;
+        pm.meta = meta_dev.as<MonoSeq>();
+        memcpy(pm.ref_xi, ref.xi, sizeof pm.ref_xi);
+        pm.ref_id = ref.id; pm.n_total = (int)hist.size();
+        pm.frame_id = frame.id; pm.max_frames = cfg.keyframe_max_frames; pm.min_translation = cfg.keyframe_min_translation;
+        pm.enabled = 1;
+    }
+    DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
+    bool decided = false;
+    if (trkM.persist_used) {
+        float rel[6], Trel[16];
+        DVO_TRY(trkM.wait_host_result(stream, rel, Trel));   // (a launch that gave up is re-run launch by launch in there: persist_used is false then)
+        if (trkM.persist_used) {
+            memcpy(h_meta.rel_xi, rel, sizeof h_meta.rel_xi);
+            memcpy(h_meta.frame_xi, trkM.h_result + 24, sizeof h_meta.frame_xi);
+            memcpy(h_meta.T_world, trkM.h_result + 30, sizeof h_meta.T_world);
+            h_meta.need = reinterpret_cast<const int*>(trkM.h_result)[46];
+            decided = true;
+        }
+    }
+    if (!decided) {
+        launch_mono_decide(meta_dev.as<MonoSeq>(), trkM.state.as<SeqState>(), 1, frame.id, cfg.keyframe_min_translation, cfg.keyframe_max_frames,
+                           nullptr, nullptr, nullptr, &hdr, stream);
+        DVO_HIP(hipMemcpyAsync(h_pin, meta_dev.p, sizeof(MonoSeq), hipMemcpyDeviceToHost, stream));
+        DVO_HIP(hipStreamSynchronize(stream));
+        memcpy(&h_meta, h_pin, sizeof h_meta);
+    }
     log_src = &trkM;   // (the 15 KB per-iteration log is read back when dvo_vo_last_track_log asks for it)
     memcpy(frame.rel_xi, h_meta.rel_xi, sizeof frame.rel_xi);
     memcpy(frame.xi, h_meta.frame_xi, sizeof frame.xi);

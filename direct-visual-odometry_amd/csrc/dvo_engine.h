@@ -32,16 +32,29 @@ int check_hip(hipError_t e, const char* what);
         if (_st != DVO_OK) return _st;                             \
     } while (0)
 
-struct DevBuf {  // RAII hipMalloc
+struct DevBuf {  // RAII hipMalloc (or a view of memory somebody else owns: adopt())
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     int alloc(size_t n);
+    void adopt(void* mem, size_t n) { release(); p = mem; bytes = n; owned = false; }
     void release();
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Device memory for the keyframes of one dvo_vo handle: FrameHistory grows by one Frame per keyframe (frame.hpp:151-157), and a hipMalloc
+// per map of every new keyframe costs more than tracking a frame.  Blocks of one keyframe's size are cut from slabs of 16 and recycled
+// when a keyframe is dropped (dvo_vo_set_history_limit).
+struct KeyframePool {
+    size_t block_bytes = 0;
+    std::vector<std::unique_ptr<DevBuf>> slabs;
+    std::vector<void*> free_blocks;
+    int take(size_t bytes, void** out);
+    void give(void* blk) { free_blocks.push_back(blk); }
 };
 
 struct Geometry {  // pyramid shape of Frame(gray, K, levels, culls): frame.hpp:91-117, frame.cpp:30-37
@@ -71,7 +84,8 @@ struct FrameSet {  // n_seq frames: gray/depth/sigma pyramids, level l stored as
     float wgt_valid[DVO_MAX_LEVELS] = {0};
     float step[DVO_MAX_LEVELS] = {0};
     float sigma_min = 0.01f, sigma_max = 0.5f;
-    int alloc(const Geometry& geo, int n, const dvo_config& cfg);
+    int alloc(const Geometry& geo, int n, const dvo_config& cfg, void* mem = nullptr);   // mem: caller-owned block of arena_bytes()
+    static size_t arena_bytes(const Geometry& geo, int n) { return 4 * geo.px_total * (size_t)n * sizeof(float); }
 };
 
 // Builds pyramids of (gray, depth, sigma) device inputs [n_seq][src_h][src_w]; depth/sigma may be null.
@@ -147,6 +161,8 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
     float* h_result = nullptr;   // host view: [0..5] xi, [6..21] T, [22] tag (int), [23] tag of a persistent launch that gave up
     float* d_result = nullptr;   // device view of the same memory
     int result_tag = 0;
+    PersistMono mono_tail = {};    // armed by a mono dvo_vo handle before track(): k_track_persist also does k_mono_decide's work
+    int persist_ppt = 0;           // pixels per thread of the one-launch schedule: 0 = 4, > 0 = that many, < 0 = what the other schedules pick
     int enable_host_result();
     int wait_host_result(hipStream_t s, float xi[6], float T[16]);   // of the last track() call
     // profiling (cfg.profile)
@@ -166,9 +182,14 @@ struct Tracker {  // Track::Tracker for n_seq sequences at once
 struct Keyframe {  // System::Frame of one sequence, plus the age map and pose (frame.hpp:72-144)
     FrameSet fs;
     DevBuf age;    // top-level [h][w]
+    DevBuf depth_alt;              // second top-level depth map: k_regularize_redecimate writes the regularized map beside the one it reads
+    float* depth_spare = nullptr;  // whichever of the arena's top-level block and depth_alt fs.depth[top] does not point to
     float xi[6] = {0, 0, 0, 0, 0, 0}, rel_xi[6] = {0, 0, 0, 0, 0, 0};
     int id = -1, ref_id = -1;
-    int alloc(const Geometry& g, const dvo_config& cfg);
+    KeyframePool* pool = nullptr;  // where `block` (the memory of all three buffers) goes back to
+    void* block = nullptr;
+    int alloc(const Geometry& g, const dvo_config& cfg, KeyframePool* from = nullptr);
+    ~Keyframe() { if (pool && block) pool->give(block); }
 };
 
 struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
@@ -180,6 +201,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     Geometry geoM, geoD;  // Frame(gray,K,3,2) (system.hpp:47) and Frame(g,d,s,K,4,1) (system.hpp:82)
     Tracker trkM, trkD;
     bool trkM_ready = false, trkD_ready = false;
+    KeyframePool kf_pool;                              // (declared before the keyframes: destroyed after them)
     std::vector<std::unique_ptr<Keyframe>> hist;       // FrameHistory, oldest first
     std::unique_ptr<Keyframe> scratch;                 // the frame being processed (promoted on keyframe)
     std::unique_ptr<Keyframe> depth_ref, depth_cur;    // m_ref_frame of odometrizeUsingDepth
@@ -215,7 +237,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     // the maps of one frame go up on separate streams: three strided copies queued on one stream run one after the other with
     // ~9 us between them (98 us from the end of one frame's tracking to the next pyramid, profiles/r03_single_hip_trace.txt)
     hipStream_t ustream[2] = {nullptr, nullptr};
-    hipEvent_t uevent[2] = {nullptr, nullptr};
+    hipEvent_t uevent[3] = {nullptr, nullptr};
     int upload_streams();
     bool side_built = false;   // uevent[1] marks a depth / sigma pyramid built on the side stream (odometrize_depth)
     bool decimate_host_rows = getenv("DVO_UPLOAD_FULL_FRAMES") == nullptr;  // as Batch::decimate_host_rows

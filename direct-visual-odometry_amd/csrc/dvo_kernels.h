@@ -117,6 +117,15 @@ struct PersistLevel {
     GnParams prm;
     int blk_first, blk_count, t_shift, x_org, y_org, tiles_x, t2d, level_pixels;
 };
+struct MonoSeq;
+struct PersistMono {       // optional tail of k_track_persist for a mono dvo_vo handle: what k_mono_decide does, by the solver's thread, in the
+    MonoSeq* meta;         // same launch -- the pose, the keyframe decision and the world pose reach the host with the tracker's tag
+    float ref_xi[6];       // the reference keyframe (the host keeps FrameHistory): MonoRef's fields
+    int ref_id, n_total;
+    int frame_id, max_frames;
+    float min_translation;
+    int enabled;
+};
 struct PersistArgs {
     PersistLevel lv[DVO_MAX_LEVELS];
     int levels;
@@ -127,7 +136,9 @@ struct PersistArgs {
     int max_iterations, fixed_iterations;
     float min_update, min_residual;
     float* xi_out; float* T_out;
-    float* host_result;    // fine-grained mapped host memory: [0..5] xi, [6..21] T, [22] tag, [23] tag of a launch that gave up
+    float* host_result;    // fine-grained mapped host memory: [0..5] xi, [6..21] T, [22] tag, [23] tag of a launch that gave up;
+                           // with `mono`: [24..29] frame_xi, [30..45] T_world, [46] need (written before the tag)
+    PersistMono mono;
     int host_tag;          // unique per launch: also the base of this launch's epoch numbers
     int spin_limit;        // polls of the epoch word before a workgroup gives up (every wait in the kernel is bounded)
     long long* dbg;        // optional [2][64][8] wall-clock stamps (100 MHz) of the solver and of worker 0 per step (tools/persist_timeline.py)
@@ -205,6 +216,30 @@ struct MonoSeq {          // Mapper + FrameHistory state of one sequence (mapper
                           // keyframe instead (UpdateArgs::clamp_age; 0 for a history that holds every keyframe, as the reference's)
 };
 
+// What System::VisualOdometry::odometrize does between Tracker::track and Mapper::estimate (system.hpp:57-73, frame.cpp:7-14,
+// mapper.cpp:45-60) for one sequence, in the double-precision pose algebra of dvo_math.h: rel_xi <- the tracker's twist, frame_xi <-
+// concatenate(ref_xi, rel_xi), need <- needNewFrame, rel_pose <- exp(+rel_xi), T_world <- exp(frame_xi).  Shared by k_mono_decide and
+// k_track_persist's mono tail: the same operations, the same bits.
+__device__ __forceinline__ int mono_decide_one(MonoSeq& m, const float rel[6], int frame_id, float min_translation, int max_frames, float fx[6],
+                                               float T[16])
+{
+    float ref[6];
+    for (int i = 0; i < 6; i++) ref[i] = m.ref_xi[i];
+    se3_concatenate_f(ref, rel, fx);
+    const double tn2 = (double)rel[0] * rel[0] + (double)rel[1] * rel[1] + (double)rel[2] * rel[2];
+    const int need = (sqrt(tn2) > (double)min_translation || (frame_id - m.ref_id >= max_frames)) ? 1 : 0;  // mapper.cpp:45-60
+    se3_exp_f(fx, T);
+    Pose rp;
+    pose_from_xi(rel, 1.0f, rp);
+    for (int i = 0; i < 6; i++) { m.rel_xi[i] = rel[i]; m.frame_xi[i] = fx[i]; }
+    m.rel_pose = rp;
+    for (int i = 0; i < 16; i++) m.T_world[i] = T[i];
+    m.frame_id = frame_id;
+    m.need = need;
+    m.valid_updates = 0;
+    return need;
+}
+
 struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::update, mapper.cpp:99-107)
     Pose  pose;        // exp(-r_xi), r_xi = concatenate(obj.xi, -born.xi)
     float tneg[3];     // -r_xi[0:3] (twist part; implement.cpp:56)
@@ -217,6 +252,7 @@ struct AgeTableArgs {  // k_age_table: AgeEntry of every retained keyframe, once
     AgeEntry* ages;          // [n_seq][R], indexed by HISTORY index (0 = oldest retained keyframe)
     int n_seq, R;
     int n_hist;              // >= 0: explicit history length and slot = index (single handle); < 0: ring, length min(n_total, R)
+    int* zero_word = nullptr; // optional: cleared by this launch (the single handle's valid-update counter, UpdateArgs::valid_updates)
 };
 
 struct UpdateArgs {

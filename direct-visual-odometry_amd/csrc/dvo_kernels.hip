@@ -1233,9 +1233,22 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
                         for (int i = 0; i < 6; i++) { st.xi[i] = xi[i]; p.xi_out[i] = xi[i]; }
                         se3_exp_f(xi, T);
                         for (int i = 0; i < 16; i++) p.T_out[i] = T[i];
+                        float fxw[6], Tw[16];
+                        int need = 0;
+                        if (p.mono.enabled) {   // a mono handle: Frame::updateXi, needNewFrame and exp(xi) here, not in a launch of their own
+                            MonoSeq& m = *p.mono.meta;
+                            for (int i = 0; i < 6; i++) m.ref_xi[i] = p.mono.ref_xi[i];
+                            m.ref_id = p.mono.ref_id; m.n_total = p.mono.n_total;
+                            need = mono_decide_one(m, xi, p.mono.frame_id, p.mono.min_translation, p.mono.max_frames, fxw, Tw);
+                        }
                         if (p.host_result) {
                             for (int i = 0; i < 6; i++) p.host_result[i] = xi[i];
                             for (int i = 0; i < 16; i++) p.host_result[6 + i] = T[i];
+                            if (p.mono.enabled) {
+                                for (int i = 0; i < 6; i++) p.host_result[24 + i] = fxw[i];
+                                for (int i = 0; i < 16; i++) p.host_result[30 + i] = Tw[i];
+                                reinterpret_cast<int*>(p.host_result)[46] = need;
+                            }
                             __hip_atomic_store(reinterpret_cast<int*>(p.host_result + 22), p.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
                     }

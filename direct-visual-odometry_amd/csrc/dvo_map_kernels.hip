@@ -47,21 +47,9 @@ __global__ void __launch_bounds__(64) k_mono_decide(MonoSeq* meta, const SeqStat
         for (int i = 0; i < 6; i++) m.ref_xi[i] = host_ref.ref_xi[i];
         m.ref_id = host_ref.ref_id; m.n_total = host_ref.n_total;
     }
-    float rel[6], ref[6], fx[6];
-    for (int i = 0; i < 6; i++) { rel[i] = state[s].xi[i]; ref[i] = m.ref_xi[i]; }
-    se3_concatenate_f(ref, rel, fx);
-    const double tn2 = (double)rel[0] * rel[0] + (double)rel[1] * rel[1] + (double)rel[2] * rel[2];
-    const int need = (sqrt(tn2) > (double)min_translation || (frame_id - m.ref_id >= max_frames)) ? 1 : 0;  // mapper.cpp:45-60
-    float T[16];
-    se3_exp_f(fx, T);
-    Pose rp;
-    pose_from_xi(rel, 1.0f, rp);
-    for (int i = 0; i < 6; i++) { m.rel_xi[i] = rel[i]; m.frame_xi[i] = fx[i]; }
-    m.rel_pose = rp;
-    for (int i = 0; i < 16; i++) m.T_world[i] = T[i];
-    m.frame_id = frame_id;
-    m.need = need;
-    m.valid_updates = 0;
+    float rel[6], fx[6], T[16];
+    for (int i = 0; i < 6; i++) rel[i] = state[s].xi[i];
+    const int need = mono_decide_one(m, rel, frame_id, min_translation, max_frames, fx, T);
     if (need && need_list) need_list[4 + atomicAdd(&need_list[0], 1)] = s;   // (the order of the list changes no result: sequences are independent)
     if (xi_world) for (int i = 0; i < 6; i++) xi_world[s * 6 + i] = fx[i];
     if (T_world) for (int i = 0; i < 16; i++) T_world[s * 16 + i] = T[i];
@@ -101,6 +89,7 @@ __global__ void __launch_bounds__(64) k_mono_commit(MonoSeq* meta, float* hist_x
 __global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t == 0 && a.zero_word) *a.zero_word = 0;
     if (t >= a.n_seq * a.R) return;
     const int seq = t / a.R, i = t - seq * a.R;
     const MonoSeq& m = a.meta[seq];
@@ -502,7 +491,7 @@ __device__ __forceinline__ void depth_update_tail(const UpdateArgs& a, const int
         float gd = depth, gs = sigma;
         const float reset = rng_depth(a.seed, (uint32_t)obj_id, (uint32_t)i);
         if (!gaussian_update(gd, gs, nd, ns, reset)) a.ref_age[base + i] = 0.0f;  // mapper.cpp:124-127
-        else atomicAdd(m ? const_cast<int*>(&m->valid_updates) : a.valid_updates, 1);
+        else atomicAdd(a.valid_updates ? a.valid_updates : const_cast<int*>(&m->valid_updates), 1);   // (an explicit counter wins)
         a.ref_depth[base + i] = gd;                                    // mapper.cpp:130-131
         a.ref_sigma[base + i] = gs;
     }

@@ -92,7 +92,7 @@ int dvo_vo_load(dvo_vo* vo, const char* path)
     bool ok = true;
     for (int i = 0; i < h.n_keyframes && ok; i++) {
         auto k = std::make_unique<Keyframe>();
-        int st = k->alloc(v.geoM, v.cfg);
+        int st = k->alloc(v.geoM, v.cfg, &v.kf_pool);
         if (st != DVO_OK) { fclose(f); return st; }
         int32_t ids[2];
         ok = get(f, ids, sizeof ids) && get(f, k->xi, sizeof k->xi) && get(f, k->rel_xi, sizeof k->rel_xi);

@@ -3,6 +3,7 @@ LOUDLY (no CPU fallback) when asked to compute without a GPU.  No compute call s
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -25,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(dvo.EXPORTS) == names          # the Python binding list and the header agree
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    # The engine's C++ types live in namespace dvo, like the facade's (include/dvo.hpp): an exported dvo::Keyframe::~Keyframe() of
+    # the library is resolved to the host PROGRAM's dvo::Keyframe by the dynamic linker (seen: a segfault in free()).
+    so = os.path.join(ROOT, "direct-visual-odometry_amd", "lib", "libdvo.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names and all(n.startswith("dvo_") for n in names), [n for n in names if not n.startswith("dvo_")][:10]
+    assert sorted(names) == _header_functions()
 
 
 def test_config_defaults_are_the_reference_literals():

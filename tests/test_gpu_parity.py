@@ -718,6 +718,41 @@ def test_single_handle_schedules_give_the_same_bits(monkeypatch):
                     np.testing.assert_array_equal(a["residual"][l], b["residual"][l])
 
 
+def test_mono_handle_schedules_give_the_same_bits(monkeypatch):
+    """A dvo_vo handle's mono loop (odometrize: track + Mapper::estimate + regularize, system.hpp:44-74) on its schedules: the default
+    (k_track_persist with the keyframe decision as its tail, pose and decision through mapped host memory), the persistent kernel's
+    give-up path (polling limit 0), one launch per iteration + k_mono_decide, and launch pairs.  World poses, keyframe flags,
+    valid-update counts, iteration counts and the newest keyframe's depth / sigma / age maps bit for bit on every frame."""
+    g, d, _, _ = frames(12, seed=42, sigma=0.1)
+    d0 = d[0][::4, ::4].copy()
+    runs = {}
+    for name, (sl, limit) in {"persist": (0, None), "persist_gives_up": (0, "0"), "per_iteration": (1, None), "pairs": (-1, None)}.items():
+        if limit is None:
+            monkeypatch.delenv("DVO_PERSIST_SPIN_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("DVO_PERSIST_SPIN_LIMIT", limit)
+        vo = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(track_single_launch=sl, rng_seed=3))
+        vo.setInitialDepth(d0, np.full_like(d0, 0.5))
+        out = []
+        for i in range(12):
+            T, key = vo.odometrize(g[i])
+            kf = vo.keyframe(vo.keyframeCount() - 1)
+            out.append((T.copy(), bool(key), vo.lastValidUpdates(), vo.lastTrackLog()["n_iter"] if i > 0 else None,
+                        kf["depth"].copy(), kf["sigma"].copy(), kf["age"].copy(), vo.keyframeCount()))
+        vo.close()
+        runs[name] = out
+    monkeypatch.delenv("DVO_PERSIST_SPIN_LIMIT", raising=False)
+    ref = runs["pairs"]
+    assert sum(r[1] for r in ref) >= 2 and sum(not r[1] for r in ref) >= 3   # both branches of Mapper::estimate ran (the update counts on real frames: test_real_data.py)
+    for name in ("persist", "persist_gives_up", "per_iteration"):
+        for i in range(12):
+            a, b = runs[name][i], ref[i]
+            np.testing.assert_array_equal(a[0].view(np.uint32), b[0].view(np.uint32), err_msg="%s frame %d" % (name, i))
+            assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[7] == b[7], (name, i, a[1:4], b[1:4])
+            for k in (4, 5, 6):
+                np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32), err_msg="%s frame %d map %d" % (name, i, k))
+
+
 def test_single_handle_one_launch_schedule_edge_cases():
     """k_track_persist (one launch per odometrizeUsingDepth call) where its control flow is unusual: a fixed iteration count (the
     level never 'stops' by a threshold), a reference without any usable depth (every step has zero contributing pixels: residual -1,

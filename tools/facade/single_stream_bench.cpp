@@ -2,6 +2,7 @@
 // frame, one sequence, synchronous) timed from C++ through include/dvo.hpp, with no Python in the measurement: float maps from
 // pageable and from pinned host memory, and raw u8 + u16 sensor frames.  Frames come from a raw float32 file ([n][3][h][w]: gray,
 // depth, sigma) written by the caller (tools/bench_single_cpp.py).
+// Then the mono loop (main.cpp:49).
 //   single_stream_bench <frames.f32> <n> <w> <h> <fx> <fy> <cx> <cy> <frames_to_time>
 #include <hip/hip_runtime_api.h>
 
@@ -28,7 +29,7 @@ int main(int argc, char** argv)
     std::fclose(f);
     auto idx = [&](int k) { const int period = 2 * (n - 1), r = k % period; return r < n ? r : period - r; };   // ping-pong: neighbours only
     try {
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = std::getenv("DVO_SKIP_DEPTH") ? 3 : 0; mode < 3; mode++) {
             // mode 0: float maps in pageable memory (what cv::Mat1f buffers are); 1: the same in pinned memory; 2: raw u8 gray + u16 depth
             float* pin = nullptr;
             std::vector<uint8_t> g8; std::vector<uint16_t> d16;
@@ -71,6 +72,43 @@ int main(int argc, char** argv)
                                                                                                    : "odometrizeUsingDepthRaw, u8 gray + u16 depth",
                         N / dt, dt / N * 1e6, (double)its / N);
             if (pin) (void)hipHostFree(pin);
+        }
+        // mono: the reference's main loop (main.cpp:49: `T = vo.odometrize(gray)`), tracking + Mapper::estimate + regularize per frame;
+        // initial map = the first frame's depth decimated by 4 with sigma 0.5 (a map the stereo updates succeed on), float gray from
+        // pageable host memory, then raw u8 gray
+        if (!std::getenv("DVO_SKIP_MONO")) {
+            const int tw = w / 4, th = h / 4;
+            std::vector<float> d0((size_t)tw * th), s0((size_t)tw * th, 0.5f);
+            for (int y = 0; y < th; y++)
+                for (int x = 0; x < tw; x++) d0[(size_t)y * tw + x] = frames[px + (size_t)(4 * y) * w + 4 * x];
+            std::vector<uint8_t> g8((size_t)n * px);
+            for (int i = 0; i < n; i++)
+                for (size_t p = 0; p < px; p++) g8[i * px + p] = (uint8_t)std::lrintf(std::fmin(std::fmax(frames[(size_t)i * 3 * px + p] * 255.0f, 0.0f), 255.0f));
+            for (int mode = 0; mode < 2; mode++) {
+                dvo_config cfg = dvo::default_config();
+                cfg.rng_seed = 1;
+                dvo::VisualOdometry vo(K, w, h, &cfg);
+                vo.setInitialDepth(d0.data(), s0.data());
+                double t0 = 0;
+                int keys = 0;
+                long its = 0;
+                for (int k = 0; k < N + 3; k++) {
+                    if (k == 3) t0 = now();
+                    const int i = idx(k);
+                    bool key = false;
+                    if (mode == 0) (void)vo.odometrize(frames.data() + (size_t)i * 3 * px, &key);
+                    else (void)vo.odometrizeRaw(g8.data() + i * px, 1, &key);
+                    if (k >= 3) keys += key ? 1 : 0;
+                }
+                const double dt = now() - t0;
+                {   // (outside the timed loop) iterations of the last frame
+                    const dvo_track_log lg = vo.lastTrackLog();
+                    for (int l = 0; l < lg.levels; l++) its += lg.n_iter[l];
+                }
+                std::printf("%-52s %8.1f frames/s  %7.1f us/frame  (%d keyframes in %d frames; last frame: %ld GN iterations)\n",
+                            mode == 0 ? "odometrize (mono: track + map), float gray, pageable" : "odometrizeRaw (mono: track + map), u8 gray", N / dt,
+                            dt / N * 1e6, keys, N, its);
+            }
         }
     } catch (const dvo::Error& e) {
         std::fprintf(stderr, "dvo error %d: %s\n", e.status, e.what());
