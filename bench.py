@@ -584,6 +584,10 @@ def run_depth(a, env, role="headline", data=None):
                 if m:
                     key = "float_pageable" if "pageable" in m.group(1) else ("float_pinned" if "pinned" in m.group(1) else "raw_u8_u16")
                     cpp[key] = {"fps": float(m.group(2)), "us_per_frame": float(m.group(3)), "gn_iterations_per_frame": float(m.group(4))}
+                m = re.match(r"^(odometrize\S*) \(mono.*?\s+([\d.]+) frames/s\s+([\d.]+) us/frame\s+\((\d+) keyframes in (\d+) frames", line)
+                if m:   # the reference's main loop (main.cpp:49: vo.odometrize(gray) per frame): tracking + Mapper::estimate + regularize
+                    cpp["mono_raw_u8" if "Raw" in m.group(1) else "mono_float_pageable"] = {
+                        "fps": float(m.group(2)), "us_per_frame": float(m.group(3)), "keyframes": int(m.group(4)), "frames": int(m.group(5))}
             if not cpp:
                 cpp = {"error": (r.stderr or r.stdout)[-300:]}
         out["secondary"] = {"single_stream_odometrizeUsingDepth_fps": single_depth, "single_stream_odometrizeUsingDepthRaw_fps": single_raw,
@@ -897,7 +901,7 @@ def run_mono(a, env, role="headline", gray=None):
                            "note": "camera positions of sequence 0 over the timed frames, GPU batch vs the CPU oracle run on the same frames with "
                                    "the same initial map (unaligned); the mapping amplifies last-bit pose differences frame over frame "
                                    "(DESIGN.md §6), so agreement decays along the sequence"}
-        if head:
+        if True:   # (a side leg gets a shorter sample)
             def cpu(budget):
                 vo = orc.OVO(K, W, H, seed=1, variant=1)
                 vo.set_initial_depth(d0, np.full_like(d0, 0.5))
@@ -906,9 +910,10 @@ def run_mono(a, env, role="headline", gray=None):
                 while time.perf_counter() - t0 < budget:
                     vo.odometrize(g0[ring_index(1 + n, F)]); n += 1
                 return n / (time.perf_counter() - t0), n
-            one, n1 = cpu(a.cpu_seconds * 0.5)
+            budget = a.cpu_seconds * 0.5 if head else 2.5
+            one, n1 = cpu(budget)
             orc.set_threads(env.ncore)
-            allc, na = cpu(a.cpu_seconds * 0.5)
+            allc, na = cpu(budget)
             orc.set_threads(1)
             out["cpu_baseline"] = {"value": allc, "unit": "frames/s", "cores": env.ncore, "kind": "port",
                                    "sample": "%d frames of sequence 0 through the oracle's VisualOdometry::odometrize ('faithful' tracker variant, "
@@ -942,7 +947,15 @@ def main():
             # BASELINE configs[2]: the mono pipeline on the first 8192 sequences' gray frames (already in HBM)
             am = copy.copy(a); am.workload = "syn640-mono"; am.batch = min(8192, a.batch); am.steps = min(a.steps, 20); am.warmup = min(a.warmup, 3)
             data["depth16_keep"] = data["depth16"]
-            sec["mono_batch"] = _brief(run_mono(am, env, role="secondary", gray=data["gray8"]), extra=("metric",))
+            sec["mono_batch"] = _brief(run_mono(am, env, role="secondary", gray=data["gray8"]), extra=("metric", "cpu_baseline"))
+            cppm = (sec.get("single_stream_cpp") or {}).get("mono_float_pageable")
+            cbm = sec["mono_batch"].get("cpu_baseline")
+            if cppm and cbm:   # the reference's main loop (main.cpp:49) as one stream, against the CPU oracle's odometrize on the same kind of frames
+                sec["single_stream_mono_vs_cpu_baseline"] = {"single_stream_fps": cppm["fps"], "x_all_cores": cppm["fps"] / cbm["value"],
+                                                             "x_one_core": cppm["fps"] / cbm["one_core"]["value"],
+                                                             "note": "vo.odometrize(gray) per frame from C++ through include/dvo.hpp (float gray from pageable "
+                                                                     "host memory, tracking + Mapper::estimate + regularize) against the CPU oracle's "
+                                                                     "VisualOdometry::odometrize"}
             # a converging configuration beside the headline (the reference's constants cannot converge at sigma = 0.1): step literals
             # halved and sigma 0.5 -> the update IS the Gauss-Newton step (gain 1 at levels 0 and 3), stop on the update norm only
             ac = copy.copy(a); ac.batch = min(1024, a.batch); ac.sigma = 0.5; ac.input = "float"; ac.step_scale = 0.5; ac.min_residual = 0.0
