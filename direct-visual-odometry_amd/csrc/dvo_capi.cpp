@@ -836,4 +836,41 @@ int dvo_selftest_reciprocal(int dev, uint64_t* fast_path_inputs, uint64_t* misma
     return DVO_OK;
 }
 
+int dvo_selftest_sqrt(int dev, uint64_t* inputs, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    if (!mismatches) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(dev));
+    DevBuf out;
+    DVO_TRY(out.alloc(3 * sizeof(unsigned long long)));
+    unsigned long long h[3] = {0ull, 0ull, ~0ull};
+    DVO_HIP(hipMemcpy(out.p, h, sizeof h, hipMemcpyHostToDevice));
+    launch_selftest_sqrt(out.as<unsigned long long>(), nullptr);
+    DVO_HIP(hipDeviceSynchronize());
+    DVO_HIP(hipMemcpy(h, out.p, sizeof h, hipMemcpyDeviceToHost));
+    if (inputs) *inputs = h[0];
+    *mismatches = h[1];
+    if (first_bad_bits) *first_bad_bits = (uint32_t)h[2];
+    return DVO_OK;
+}
+
+int dvo_selftest_division(int dev, uint32_t b_first, uint32_t b_stride, uint32_t b_count, uint64_t* pairs, uint64_t* mismatches, uint64_t* first_bad_pair)
+{
+    if (!mismatches || b_count == 0 || b_count > (1u << 23)) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(dev));
+    DevBuf out;
+    DVO_TRY(out.alloc(3 * sizeof(unsigned long long)));
+    unsigned long long h[3] = {0ull, 0ull, ~0ull};
+    DVO_HIP(hipMemcpy(out.p, h, sizeof h, hipMemcpyHostToDevice));
+    for (uint32_t done = 0; done < b_count; done += 1u << 17) {   // 2^17 values of b (x 2^23 of a) per launch: each well under a second
+        const uint32_t n = b_count - done < (1u << 17) ? b_count - done : (1u << 17);
+        launch_selftest_division(b_first + done * b_stride, b_stride, n, out.as<unsigned long long>(), nullptr);
+        DVO_HIP(hipDeviceSynchronize());
+    }
+    DVO_HIP(hipMemcpy(h, out.p, sizeof h, hipMemcpyDeviceToHost));
+    if (pairs) *pairs = h[0];
+    *mismatches = h[1];
+    if (first_bad_pair) *first_bad_pair = h[2];
+    return DVO_OK;
+}
+
 }  // extern "C"

@@ -362,6 +362,8 @@ void launch_regularize(const float* depth, const float* sigma, int w, int h, flo
 void launch_depth_update(const UpdateArgs& a, hipStream_t s);
 void launch_ingest(const uint8_t* rgb, int channels, const uint16_t* depth16, int n, float depth_scale, float sigma_valid,
                    float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma, hipStream_t s);
+void launch_selftest_sqrt(unsigned long long* out3, hipStream_t s);          // out3 = {inputs, mismatches, first bad pattern}, pre-set {0, 0, ~0}
+void launch_selftest_division(unsigned b_first, unsigned b_stride, unsigned b_count, unsigned long long* out3, hipStream_t s);   // (at most 2^17 values of b per launch)
 void launch_selftest_reciprocal(unsigned long long* out3, hipStream_t s);  // out3 = {fast-path inputs, mismatches, first bad pattern}, pre-set {0, 0, ~0}
 void launch_visualize(int mode, const float* a, const float* b, int n, uint8_t* rgb, hipStream_t s);
 void launch_undistort(const float* src, int w, int h, const Intr& k, const float D[5], float border, float* dst, hipStream_t s);

@@ -1554,6 +1554,46 @@ __global__ void __launch_bounds__(256) k_selftest_reciprocal(unsigned long long*
     atomicMin(&out[2], first);
 }
 
+// k_selftest_sqrt: sqrt_fast() (dvo_math.h; the regularize kernels' square root) against sqrtf for every float in [2^-100, 2^100].
+// k_selftest_division: div_by_recip(a, b, recip_fast(b)) against a / b for b = 1.mb, mb = b_first + i * b_stride (i < b_count), and ALL
+// 2^23 mantissas of a in [1, 2) -- the operations after v_rcp_f32 (whose every input recip_fast() was enumerated on:
+// k_selftest_reciprocal) are IEEE multiplies and FMAs, scale invariant inside the normal range, so mantissa pairs are all there is to check.
+// out = {operands checked, mismatches, first bad (sqrt: bit pattern; division: mb << 23 | ma)}, pre-set {0, 0, ~0}.
+__global__ void __launch_bounds__(256) k_selftest_sqrt(unsigned long long* out)
+{
+    unsigned long long n = 0, bad = 0, first = ~0ull;
+    for (unsigned long long p = blockIdx.x * 256ull + threadIdx.x; p < (1ull << 31); p += (unsigned long long)gridDim.x * 256ull) {
+        const float x = __uint_as_float((unsigned)p);
+        if (!(x >= DVO_RECIP_FAST_MIN && x <= DVO_RECIP_FAST_MAX)) continue;
+        n++;
+        if (__float_as_uint(sqrt_fast(x)) != __float_as_uint(sqrtf(x))) { bad++; if (p < first) first = p; }
+    }
+    atomicAdd(&out[0], n);
+    if (bad) { atomicAdd(&out[1], bad); atomicMin(&out[2], first); }
+}
+
+__global__ void __launch_bounds__(256) k_selftest_division(unsigned b_first, unsigned b_stride, unsigned b_count, unsigned long long* out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= b_count) return;
+    const unsigned mb = (b_first + i * b_stride) & 0x7fffffu;
+    const float b = __uint_as_float(0x3f800000u | mb);
+    const float y = recip_fast(b);
+    unsigned long long bad = 0, first = ~0ull;
+    for (unsigned ma = 0; ma < (1u << 23); ma++) {
+        const float a = __uint_as_float(0x3f800000u | ma);
+        if (__float_as_uint(div_by_recip(a, b, y)) != __float_as_uint(a / b)) { bad++; const unsigned long long k = ((unsigned long long)mb << 23) | ma; if (k < first) first = k; }
+    }
+    atomicAdd(&out[0], 1ull << 23);
+    if (bad) { atomicAdd(&out[1], bad); atomicMin(&out[2], first); }
+}
+
+void launch_selftest_sqrt(unsigned long long* out, hipStream_t s) { hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, s, out); }
+void launch_selftest_division(unsigned b_first, unsigned b_stride, unsigned b_count, unsigned long long* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_division, dim3((b_count + 255) / 256), dim3(256), 0, s, b_first, b_stride, b_count, out);
+}
+
 void launch_selftest_reciprocal(unsigned long long* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_selftest_reciprocal, dim3(8192), dim3(256), 0, s, out);

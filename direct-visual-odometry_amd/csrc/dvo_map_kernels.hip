@@ -220,6 +220,26 @@ __device__ __forceinline__ void regularize_fuse4(const float* __restrict__ depth
     const int iL = hasL ? i - 1 : i, iR = hasR ? i + 1 : i, iD = hasD ? i + w : i, iU = hasU ? i - w : i;
     const float dL = depth[iL], sL = sigma[iL], dR = depth[iR], sR = sigma[iR];
     const float dD = depth[iD], sD = sigma[iD], dU = depth[iU], sU = sigma[iU];
+    // Are all ten operands positive normal floats in [2^-20, 2^20]?  As unsigned integers their bit patterns order like the floats,
+    // negative values, infinities and NaNs lie above every positive finite one, zeros and subnormals below 2^-20: one min / max tree.
+    // (A neighbour that does not exist was loaded from the centre: in range if the centre is.)  Then the eight divisions and four
+    // square roots of the fusions take their verified short forms (dvo_math.h); otherwise -- a wave-uniform branch no real map takes --
+    // the IEEE sequences.  Same bits either way.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned b0 = __float_as_uint(gd), b1 = __float_as_uint(gs), b2 = __float_as_uint(dL), b3 = __float_as_uint(sL), b4 = __float_as_uint(dR),
+                   b5 = __float_as_uint(sR), b6 = __float_as_uint(dD), b7 = __float_as_uint(sD), b8 = __float_as_uint(dU), b9 = __float_as_uint(sU);
+    const unsigned lo = min(min(min(b0, b1), min(b2, b3)), min(min(b4, b5), min(min(b6, b7), min(b8, b9))));
+    const unsigned hi = max(max(max(b0, b1), max(b2, b3)), max(max(b4, b5), max(max(b6, b7), max(b8, b9))));
+    const bool ranged = (lo >= DVO_FUSE_RANGE_LO) & (hi <= DVO_FUSE_RANGE_HI);
+    if (__builtin_amdgcn_ballot_w64(!ranged) == 0ull) {
+        if (hasL) gaussian_fuse_ranged(gd, gs, dL, sL);
+        if (hasR) gaussian_fuse_ranged(gd, gs, dR, sR);
+        if (hasD) gaussian_fuse_ranged(gd, gs, dD, sD);
+        if (hasU) gaussian_fuse_ranged(gd, gs, dU, sU);
+        return;
+    }
+    asm volatile("; regularize_fuse4: IEEE division / square root");
+#endif
     if (hasL) gaussian_fuse(gd, gs, dL, sL);
     if (hasR) gaussian_fuse(gd, gs, dR, sR);
     if (hasD) gaussian_fuse(gd, gs, dD, sD);

@@ -65,7 +65,7 @@ DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float
 // result is the same bits as the oracle's x86 division.
 #define DVO_RECIP_FAST_MIN 7.888609052210118e-31f   /* 2^-100 */
 #define DVO_RECIP_FAST_MAX 1.2676506002282294e30f   /* 2^100  */
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)   // (both passes of hipcc: the host pass parses the kernels that call it)
 __device__ __forceinline__ float recip_fast(float z)  // valid for DVO_RECIP_FAST_MIN <= |z| <= DVO_RECIP_FAST_MAX
 {
     float r = __builtin_amdgcn_rcpf(z);
@@ -636,6 +636,44 @@ DVO_HD bool gaussian_fuse(float& depth, float& sigma, float d, float s)
     sigma = sqrtf((v1 * v2) / v);
     return true;
 }
+
+#if defined(__HIPCC__)
+// The same fusion for operands in a KNOWN range -- every depth and sigma a positive normal float in [2^-20, 2^20], which the caller
+// has checked (regularize_fuse4) -- without the ~11-instruction IEEE division and ~12-instruction IEEE square root sequences:
+//   a / v   = q + (a - v q) y  with  y = recip_fast(v) = RN(1 / v), q = a y            (8 instructions for the first quotient, 3 for
+//             the second: they share y);  bit-identical to the IEEE quotient for ALL 2^23 x 2^23 mantissa pairs, enumerated on the
+//             device (tools/verify/div_sqrt_exhaustive.hip, "division variant 2"; dvo_selftest_division re-checks a slice) -- and
+//             multiplies / FMAs are scale invariant while nothing leaves the normal range: here v in [2^-40, 2^41], numerators in
+//             [2^-80, 2^82], quotients in [2^-42, 2^21], residuals above 2^-110;
+//   sqrt(x) = s + (x - s s) (y / 2)  with  y = v_rsq_f32(x), s = x y                   (5 instructions);  bit-identical to sqrtf for
+//             EVERY float in [2^-100, 2^100] (same tool, "sqrt variant 1"; dvo_selftest_sqrt).
+// The fused sigma lies in [min / sqrt 2, min] and the fused depth between its inputs, so four fusions in a row stay in range.
+__device__ __forceinline__ float sqrt_fast(float x)   // == sqrtf(x) for 2^-100 <= x <= 2^100
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y;
+    return fmaf(fmaf(-s, s, x), 0.5f * y, s);
+}
+__device__ __forceinline__ float div_by_recip(float a, float v, float y)   // == a / v for y = recip_fast(v), operands as above
+{
+    const float q = a * y;
+    return fmaf(fmaf(-v, q, a), y, q);
+}
+__device__ __forceinline__ bool gaussian_fuse_ranged(float& depth, float& sigma, float d, float s)
+{  // gaussian.cpp:33-50, the operations of gaussian_fuse() in the same order
+    const float v1 = sigma * sigma, v2 = s * s, v = v1 + v2;
+    const float diff = fabsf(d - depth);
+    const float gain = gauss_gain(d, diff);
+    const float ms = sigma < s ? s : sigma;
+    if (diff > gain * ms) return false;
+    const float y = recip_fast(v);
+    depth = div_by_recip(fmaf(v1, d, v2 * depth), v, y);
+    sigma = sqrt_fast(div_by_recip(v1 * v2, v, y));
+    return true;
+}
+#define DVO_FUSE_RANGE_LO 0x35800000u   /* 2^-20 */
+#define DVO_FUSE_RANGE_HI 0x49800000u   /* 2^20  */
+#endif
 
 DVO_HD bool gaussian_update(float& depth, float& sigma, float d, float s, float reset_depth)
 {  // gaussian.cpp:12-31

@@ -96,7 +96,7 @@ EXPORTS = [
     "dvo_dataset_close", "dvo_op_ingest", "dvo_vo_odometrize_depth_raw", "dvo_op_undistort",
     "dvo_eval_ate", "dvo_eval_rpe", "dvo_pose_inverse", "dvo_traj_write_tum",
     "dvo_vo_save", "dvo_vo_load", "dvo_vo_set_history_limit", "dvo_op_visualize", "dvo_ppm_write",
-    "dvo_selftest_reciprocal",
+    "dvo_selftest_reciprocal", "dvo_selftest_sqrt", "dvo_selftest_division",
 ]
 
 _lib = None
@@ -355,6 +355,20 @@ def selftest_reciprocal(dev=0):
     """All 2^32 float patterns through the kernels' reciprocal vs the IEEE division: (fast-path inputs, mismatches, first bad bits)."""
     n = C.c_uint64(); bad = C.c_uint64(); first = C.c_uint32()
     _check(lib().dvo_selftest_reciprocal(dev, C.byref(n), C.byref(bad), C.byref(first)))
+    return n.value, bad.value, first.value
+
+
+def selftest_sqrt(dev=0):
+    """Every float in [2^-100, 2^100] through the regularize kernels' short square root vs sqrtf: (inputs, mismatches, first bad bits)."""
+    n = C.c_uint64(); bad = C.c_uint64(); first = C.c_uint32()
+    _check(lib().dvo_selftest_sqrt(dev, C.byref(n), C.byref(bad), C.byref(first)))
+    return n.value, bad.value, first.value
+
+
+def selftest_division(b_first=0, b_stride=1, b_count=1 << 23, dev=0):
+    """The regularize kernels' short division vs the IEEE quotient for b_count mantissas of b times all 2^23 of a: (pairs, mismatches, first bad pair)."""
+    n = C.c_uint64(); bad = C.c_uint64(); first = C.c_uint64()
+    _check(lib().dvo_selftest_division(dev, C.c_uint32(b_first), C.c_uint32(b_stride), C.c_uint32(b_count), C.byref(n), C.byref(bad), C.byref(first)))
     return n.value, bad.value, first.value
 
 

@@ -337,6 +337,13 @@ int dvo_ppm_write(const char* path, const uint8_t* rgb, int w, int h);
 /* Device self-test: the kernels' correctly rounded reciprocal (v_rcp_f32 + two FMA corrections inside [2^-100, 2^100], IEEE
  * division elsewhere) against the IEEE division for all 2^32 float bit patterns.  mismatches must come back 0. */
 int dvo_selftest_reciprocal(int device, uint64_t* fast_path_inputs, uint64_t* mismatches, uint32_t* first_bad_bits);
+/* The regularize kernels' short square root (v_rsq_f32 + 4 operations) against sqrtf for every float in [2^-100, 2^100], and their
+ * short division (the reciprocal above + 3 operations) against the IEEE quotient for b = 1.mb, mb = b_first + i * b_stride
+ * (i < b_count), times ALL 2^23 mantissas of a in [1, 2); b_first = 0, b_stride = 1, b_count = 2^23 is every mantissa pair (minutes).
+ * first_bad_pair = mb << 23 | ma.  mismatches must come back 0. */
+int dvo_selftest_sqrt(int device, uint64_t* inputs, uint64_t* mismatches, uint32_t* first_bad_bits);
+int dvo_selftest_division(int device, uint32_t b_first, uint32_t b_stride, uint32_t b_count, uint64_t* pairs, uint64_t* mismatches,
+                          uint64_t* first_bad_pair);
 
 /* ------------------------------------------------------------------------------------------------
  * Trajectory evaluation / export.  Host side, double precision.

@@ -467,6 +467,21 @@ def test_device_reciprocal_is_ieee_for_every_float():
     assert n_fast == 2 * (200 * (1 << 23) + 1)   # both signs, exponents 2^-100 .. 2^100 (inclusive end point)
 
 
+def test_device_short_division_and_sqrt_are_ieee():
+    """k_regularize(_redecimate) runs its 8 divisions and 4 square roots per pixel as rcp / rsq + FMA corrections when every operand is a
+    normal float in [2^-20, 2^20].  Bit-exact maps rest on those being THE correctly rounded results: the square root is compared with
+    sqrtf for every float in [2^-100, 2^100]; the division for 2^14 mantissas of b spread over [1, 2) (stride 509: odd, so every
+    low-bit pattern occurs) plus the 2^10 on either end, each against ALL 2^23 mantissas of a.  (All 2^46 pairs:
+    tools/verify/division_all_pairs.py, profiles/r03_division_all_pairs.txt.)"""
+    n, bad, first = dvo.selftest_sqrt()
+    assert bad == 0, "first mismatching bit pattern 0x%08x" % first
+    assert n == 200 * (1 << 23) + 1
+    for (b0, stride, cnt) in ((0, 509, 1 << 14), (0, 1, 1 << 10), ((1 << 23) - (1 << 10), 1, 1 << 10)):
+        n, bad, first = dvo.selftest_division(b0, stride, cnt)
+        assert n == cnt << 23
+        assert bad == 0, "first mismatching pair: mb = 0x%06x, ma = 0x%06x" % (first >> 23, first & 0x7fffff)
+
+
 def test_adaptive_schedule_changes_no_result():
     """track_adaptive (default): the host stops a level's launches once a launch reported no active sequence.  Skipped launches
     are empty ones, so poses and logs must equal the fixed schedule's (track_adaptive = -1) bit for bit -- single and batch."""
