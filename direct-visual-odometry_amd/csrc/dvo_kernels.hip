@@ -415,7 +415,7 @@ __device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, 
 {  // branch free: everything is computed; decidable = no INVALID / NaN tap (else: generic path), valid = pixel contributes
     const float mn = min3_raw(min3_raw(min3_raw(t.ra.x, t.ra.y, t.rd.x), min3_raw(t.rb.x, t.rb.y, t.rb.z), min3_raw(t.rc.x, t.rc.y, t.rc.z)),
                               min3_raw(t.rd.y, t.rb.w, t.rc.w), t.rd.y);
-    const float hx = u - (float)x0, vy = v - (float)y0;
+    const float hx = u - (float)x0, vy = v - (float)y0;   // (v_fract_f32 gives the same bits for u >= 1 and saves two conversions: measured, no gain)
     I2 = blend4(t.rb.y, t.rb.z, t.rc.y, t.rc.z, hx, vy);
     gx = blend4(t.rb.z - t.rb.x, t.rb.w - t.rb.y, t.rc.z - t.rc.x, t.rc.w - t.rc.y, hx, vy);
     gy = blend4(t.rc.y - t.ra.x, t.rc.z - t.ra.y, t.rd.x - t.rb.y, t.rd.y - t.rb.z, hx, vy);

@@ -58,8 +58,8 @@ DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float
     Zo = fmaf(p.R[6], X, fmaf(p.R[7], Y, fmaf(p.R[8], Z, p.t[2])));
 }
 
-// Correctly rounded 1/z.  On the device: v_rcp_f32 (1 ulp) + two FMA correction steps (Markstein) for |z| inside
-// [2^-100, 2^100] -- 5 instructions instead of the 11 of the IEEE division sequence -- and the IEEE division
+// Correctly rounded 1/z.  On the device: v_rcp_f32 (1 ulp) + one Newton step (two FMAs) for |z| inside
+// [2^-100, 2^100] -- 3 instructions instead of the 11 of the IEEE division sequence -- and the IEEE division
 // outside that range or for non-finite z (never the case for a real depth).  The fast branch equals 1.0f / z for EVERY
 // float in its range: checked exhaustively on the device by dvo_selftest_reciprocal (tests/test_gpu_parity.py), so the
 // result is the same bits as the oracle's x86 division.
@@ -69,9 +69,8 @@ DVO_HD void transform(const Pose& p, float X, float Y, float Z, float& Xo, float
 __device__ __forceinline__ float recip_fast(float z)  // valid for DVO_RECIP_FAST_MIN <= |z| <= DVO_RECIP_FAST_MAX
 {
     float r = __builtin_amdgcn_rcpf(z);
-    r = fmaf(fmaf(-z, r, 1.0f), r, r);
-    r = fmaf(fmaf(-z, r, 1.0f), r, r);
-    return r;
+    r = fmaf(fmaf(-z, r, 1.0f), r, r);   // ONE Newton step is already the correctly rounded reciprocal of every float in range on gfx950
+    return r;                            // (enumerated: dvo_selftest_reciprocal; rounds 1-2 carried a second, redundant step)
 }
 #endif
 DVO_HD float recip_rn(float z)
@@ -640,7 +639,7 @@ DVO_HD bool gaussian_fuse(float& depth, float& sigma, float d, float s)
 #if defined(__HIPCC__)
 // The same fusion for operands in a KNOWN range -- every depth and sigma a positive normal float in [2^-20, 2^20], which the caller
 // has checked (regularize_fuse4) -- without the ~11-instruction IEEE division and ~12-instruction IEEE square root sequences:
-//   a / v   = q + (a - v q) y  with  y = recip_fast(v) = RN(1 / v), q = a y            (8 instructions for the first quotient, 3 for
+//   a / v   = q + (a - v q) y  with  y = recip_fast(v) = RN(1 / v), q = a y            (6 instructions for the first quotient, 3 for
 //             the second: they share y);  bit-identical to the IEEE quotient for ALL 2^23 x 2^23 mantissa pairs, enumerated on the
 //             device (tools/verify/div_sqrt_exhaustive.hip, "division variant 2"; dvo_selftest_division re-checks a slice) -- and
 //             multiplies / FMAs are scale invariant while nothing leaves the normal range: here v in [2^-40, 2^41], numerators in

@@ -69,6 +69,22 @@ __global__ void __launch_bounds__(256) k_sqrt(unsigned long long* out)
     if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
 }
 
+// reciprocal with ONE Newton step (recip_fast() has two): exact for every float in [2^-100, 2^100]?
+__global__ void __launch_bounds__(256) k_recip1(unsigned long long* out)
+{
+    unsigned long long bad = 0, first = ~0ull, n = 0;
+    for (unsigned long long p = blockIdx.x * 256ull + threadIdx.x; p < (1ull << 31); p += (unsigned long long)gridDim.x * 256ull) {
+        const float x = __uint_as_float((unsigned)p);
+        if (!(x >= 7.888609052210118e-31f && x <= 1.2676506002282294e30f)) continue;
+        n++;
+        float y = __builtin_amdgcn_rcpf(x);
+        y = fmaf(fmaf(-x, y, 1.0f), y, y);
+        if (__float_as_uint(1.0f / x) != __float_as_uint(y)) { bad++; if (p < first) first = p; }
+    }
+    atomicAdd(&out[2], n);
+    if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int V>
@@ -108,6 +124,16 @@ int main(int argc, char** argv)
     const int chunks = argc > 1 ? std::atoi(argv[1]) : 64;
     unsigned long long* d_out = nullptr;
     CK(hipMalloc(&d_out, 3 * sizeof(unsigned long long)));
+    {
+        unsigned long long h[3] = {0, ~0ull, 0};
+        CK(hipMemcpy(d_out, h, sizeof h, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_recip1, dim3(8192), dim3(256), 0, nullptr, d_out);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost));
+        std::printf("reciprocal with one Newton step: %llu inputs in [2^-100, 2^100]: %llu mismatches", h[2], h[0]);
+        if (h[0]) std::printf(" (first: 0x%08llx)", h[1]);
+        std::printf("\n");
+    }
     if (run_sqrt<1>(d_out) || run_sqrt<2>(d_out) || run_sqrt<3>(d_out)) return 1;
     if (run_div<1>(chunks, d_out) || run_div<2>(chunks, d_out) || run_div<3>(chunks, d_out)) return 1;
     return 0;
