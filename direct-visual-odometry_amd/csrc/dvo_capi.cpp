@@ -836,6 +836,23 @@ int dvo_selftest_reciprocal(int dev, uint64_t* fast_path_inputs, uint64_t* misma
     return DVO_OK;
 }
 
+int dvo_selftest_trig(int dev, double* max_rel_sin, double* max_rel_cos, double* max_rel_atan2, uint64_t* samples)
+{
+    if (!max_rel_sin || !max_rel_cos || !max_rel_atan2) return DVO_ERR_BAD_ARGUMENT;
+    DVO_TRY(select_device(dev));
+    DevBuf out;
+    DVO_TRY(out.alloc(3 * sizeof(unsigned long long)));
+    DVO_HIP(hipMemset(out.p, 0, out.bytes));
+    const unsigned side = 4096, n = side * side;
+    launch_selftest_trig(n, side, out.as<unsigned long long>(), nullptr);
+    DVO_HIP(hipDeviceSynchronize());
+    unsigned long long h[3];
+    DVO_HIP(hipMemcpy(h, out.p, sizeof h, hipMemcpyDeviceToHost));
+    memcpy(max_rel_sin, &h[0], 8); memcpy(max_rel_cos, &h[1], 8); memcpy(max_rel_atan2, &h[2], 8);
+    if (samples) *samples = n;
+    return DVO_OK;
+}
+
 int dvo_selftest_sqrt(int dev, uint64_t* inputs, uint64_t* mismatches, uint32_t* first_bad_bits)
 {
     if (!mismatches) return DVO_ERR_BAD_ARGUMENT;

@@ -106,6 +106,7 @@ struct SolveArgs {
     int* progress = nullptr;   // optional, mapped HOST memory: workgroup 0 stores (sequences this iteration evaluated + 1)
     int n_seq = 1;             // sequences of the launch (set by launch_gn_solve)
     int blk_first = 0, blk_count = -1;  // partial rows outside [blk_first, blk_first + blk_count) count as zero (-1: all rows)
+    long long* dbg_stamp = nullptr;     // diagnostic (k_track_persist's timeline): [0] after the 6x6 solve, [1] after the pose update
 };
 
 // k_track_persist: the whole of Tracker::track for ONE sequence in one launch (a dvo_vo handle).
@@ -362,6 +363,7 @@ void launch_regularize(const float* depth, const float* sigma, int w, int h, flo
 void launch_depth_update(const UpdateArgs& a, hipStream_t s);
 void launch_ingest(const uint8_t* rgb, int channels, const uint16_t* depth16, int n, float depth_scale, float sigma_valid,
                    float sigma_invalid, int invalidate_gray, float* gray, float* depth, float* sigma, hipStream_t s);
+void launch_selftest_trig(unsigned n, unsigned side, unsigned long long* out3, hipStream_t s);   // out3 = bits of the largest relative differences (sin, cos, atan2), pre-set 0
 void launch_selftest_sqrt(unsigned long long* out3, hipStream_t s);          // out3 = {inputs, mismatches, first bad pattern}, pre-set {0, 0, ~0}
 void launch_selftest_division(unsigned b_first, unsigned b_stride, unsigned b_count, unsigned long long* out3, hipStream_t s);   // (at most 2^17 values of b per launch)
 void launch_selftest_reciprocal(unsigned long long* out3, hipStream_t s);  // out3 = {fast-path inputs, mismatches, first bad pattern}, pre-set {0, 0, ~0}

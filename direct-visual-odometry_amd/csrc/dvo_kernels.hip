@@ -940,8 +940,10 @@ __device__ __forceinline__ int solve_finish(const SolveArgs& a, const int seq, S
         solve6(tot, tot + 21, upd);
         residual = (float)sum_r2 / (float)n_valid;  // optimize.cpp:98
     }
+    if (a.dbg_stamp) a.dbg_stamp[0] = wall_clock64();
     // xi <- log(exp(xi) exp(upd)) unless NaN (tracker.cpp:46-51); pose <- exp(-xi) for Stuff::update (optimize.hpp:26-30)
     const bool updated = se3_update_pose(Tc, upd, xi, np);
+    if (a.dbg_stamp) a.dbg_stamp[1] = wall_clock64();
     if (updated) {
 #pragma unroll
         for (int i = 0; i < 6; i++) st.xi[i] = xi[i];
@@ -1222,6 +1224,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
                 sa.min_update = p.min_update; sa.min_residual = p.min_residual;
                 sa.ignore_active = first; sa.list_in = nullptr; sa.list_out = nullptr; sa.progress = nullptr; sa.n_seq = 1;
                 sa.blk_first = L.blk_first; sa.blk_count = L.blk_count;
+                if (stamp) sa.dbg_stamp = &p.dbg[(64 + step) * 8 + 5];   // (two free slots of worker 0's row)
                 const int r = solve_finish(sa, 0, st, tot, first, it_prev, xi, Tc, np);
                 it_prev = first ? 1 : it_prev + 1;       // (= st.iter)
                 if (!(r & 2)) pose_from_xi(xi, -1.0f, np);   // update rejected (NaN, tracker.cpp:47-51): the pose stays exp(-xi) of the unchanged xi
@@ -1586,6 +1589,34 @@ __global__ void __launch_bounds__(256) k_selftest_division(unsigned b_first, uns
     }
     atomicAdd(&out[0], 1ull << 23);
     if (bad) { atomicAdd(&out[1], bad); atomicMin(&out[2], first); }
+}
+
+// k_selftest_trig: the SE(3) chain's sin / cos / atan2 (dvo_math.h: sincos_dev, atan2_dev) against the math library over their domain:
+// sample i of n -> x log-spaced in [1e-12, 1e5) (even i) or uniform in [0, 16) (odd i) for sin / cos; (s, c) = (u, 2v - 1), u in (0, 1],
+// v in [0, 1] on a sqrt(n) x sqrt(n) grid plus the same scaled by 1e-9 for atan2 (the log map feeds it sqrt(...) and a trace).
+// out[0..2] = largest relative difference (as the bits of a non-negative double) of sin, cos, atan2.
+__global__ void __launch_bounds__(256) k_selftest_trig(unsigned n, unsigned side, unsigned long long* out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const double f = ((double)i + 0.5) / (double)n;
+    const double x = (i & 1) ? 16.0 * f : exp(log(1e-12) + f * (log(1e5) - log(1e-12)));
+    double sd, cd;
+    sincos_dev(x, sd, cd);
+    const double sl = sin(x), cl = cos(x);
+    const double es = fabs(sd - sl) / fabs(sl), ec = fabs(cd - cl) / fabs(cl);
+    const unsigned gy = i / side, gx = i - gy * side;
+    double y = ((double)gy + 1.0) / (double)side, c = 2.0 * ((double)gx / (double)(side - 1)) - 1.0;
+    if (gy & 1) { y *= 1e-9; }
+    const double ad = atan2_dev(y, c), al = atan2(y, c);
+    const double ea = fabs(ad - al) / fabs(al);
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(es));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(ec));
+    atomicMax(&out[2], (unsigned long long)__double_as_longlong(ea));
+}
+void launch_selftest_trig(unsigned n, unsigned side, unsigned long long* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_trig, dim3((n + 255) / 256), dim3(256), 0, s, n, side, out);
 }
 
 void launch_selftest_sqrt(unsigned long long* out, hipStream_t s) { hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, s, out); }

@@ -296,6 +296,73 @@ DVO_HD void cross3(const double a[3], const double b[3], double o[3])
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// sin / cos / atan2 in double for the SE(3) chain ON THE DEVICE.  One Gauss-Newton step ends in a serial chain on one lane
+// (6x6 solve, exp, log, exp: solve_finish), and the math library's sin + cos pair costs ~150 instructions of it three times over.
+// The classical kernels (odd / even minimax polynomials on [-pi/4, pi/4], two-constant Cody-Waite reduction done with FMAs, arctangent by
+// four break points) give the same accuracy -- below 1 ulp, compared with the library's results over the whole domain by
+// dvo_selftest_trig -- in ~45.  Host code keeps libm (as before, host and device differ in the last bit of such calls; every pose is
+// rounded to float before anything else sees it).  Arguments outside the fast domain take the library functions.
+#if defined(__HIPCC__)
+__device__ __forceinline__ double ksin_d(double x)   // |x| <= pi/4
+{
+    const double z = x * x, v = z * x;
+    const double r = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    return fma(v, fma(z, r, -1.66666666666666324348e-01), x);
+}
+__device__ __forceinline__ double kcos_d(double x)   // |x| <= pi/4
+{
+    const double z = x * x;
+    const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                          2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * r);
+}
+__device__ __forceinline__ void sincos_dev(double x, double& s, double& c)
+{
+    const double ax = fabs(x);
+    if (ax <= 0.78539816339744830962) { s = ksin_d(x); c = kcos_d(x); return; }
+    if (ax < 1.0e5) {
+        const double k = rint(x * 0.63661977236758134308);       // x = r + k pi/2, |r| <= pi/4 (+ rounding)
+        double r = fma(-k, 1.57079632679489655800e+00, x);        // exact: both are multiples of 2^-52 and the difference is below 1
+        r = fma(-k, 6.12323399573676603587e-17, r);
+        if (fabs(r) >= 1.0e-5) {                                  // (closer to a multiple of pi/2 than that: leave it to the library's reduction)
+            const int n = (int)k & 3;
+            const double ss = ksin_d(r), cc = kcos_d(r);
+            s = (n & 1) ? cc : ss;
+            c = (n & 1) ? ss : cc;
+            if (n & 2) s = -s;
+            if ((n + 1) & 2) c = -c;
+            return;
+        }
+    }
+    s = sin(x); c = cos(x);
+}
+__device__ __forceinline__ double katan_d(double x)   // x >= 0 (inf allowed)
+{
+    double hi = 0.0, lo = 0.0;
+    bool reduced = true;
+    if (x < 0.4375) reduced = false;
+    else if (x < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; x = (2.0 * x - 1.0) / (2.0 + x); }
+    else if (x < 1.1875) { hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; x = (x - 1.0) / (x + 1.0); }
+    else if (x < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; x = (x - 1.5) / (1.0 + 1.5 * x); }
+    else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; x = -1.0 / x; }
+    const double z = x * x, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                                            9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                     -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    if (!reduced) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+__device__ __forceinline__ double atan2_dev(double y, double x)
+{
+    if (!(y > 0.0) || !(fabs(x) <= 1.0e300) || !(y <= 1.0e300) || x == 0.0) return atan2(y, x);   // zeros, negative y, NaN, infinities: the library
+    const double z = katan_d(y / fabs(x));
+    return x > 0.0 ? z : 3.14159265358979311600e+00 - (z - 1.22464679914735317720e-16);
+}
+#endif
+
 DVO_HD void se3_exp_d(const double xi[6], double R[9], double t[3])
 {  // se3.cpp:70-98 with so3::exp = cv::Rodrigues
     const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
@@ -305,15 +372,21 @@ DVO_HD void se3_exp_d(const double xi[6], double R[9], double t[3])
     if (th < 2.220446049250313e-16) {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
     } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos_dev(th, s, c);
+#else
         c = cos(th);
         s = sin(th);
-        const double c1 = 1.0 - c, rx = w[0] / th, ry = w[1] / th, rz = w[2] / th;
+#endif
+        const double ith = 1.0 / th;   // one division for the axis (and A, B below): the chain is serial, a double division ~14 dependent instructions
+        const double c1 = 1.0 - c, rx = w[0] * ith, ry = w[1] * ith, rz = w[2] * ith;
         R[0] = c + c1 * rx * rx;      R[1] = c1 * rx * ry - s * rz; R[2] = c1 * rx * rz + s * ry;
         R[3] = c1 * rx * ry + s * rz; R[4] = c + c1 * ry * ry;      R[5] = c1 * ry * rz - s * rx;
         R[6] = c1 * rx * rz - s * ry; R[7] = c1 * ry * rz + s * rx; R[8] = c + c1 * rz * rz;
     }
     if ((float)th > 1e-6f) {
-        const double A = (1.0 - c) / th2, B = (th - s) / (th2 * th);
+        const double ith = 1.0 / th, ith2 = ith * ith;
+        const double A = (1.0 - c) * ith2, B = (th - s) * (ith2 * ith);
         double wv[3], wwv[3];
         cross3(w, v, wv);
         cross3(w, wv, wwv);
@@ -328,7 +401,11 @@ DVO_HD void se3_log_d(const double R[9], const double t[3], double xi[6])
     const double a[3] = {0.5 * (R[7] - R[5]), 0.5 * (R[2] - R[6]), 0.5 * (R[3] - R[1])};
     const double s = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
     const double cth = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double th = atan2_dev(s, cth);
+#else
     const double th = atan2(s, cth);
+#endif
     double w[3] = {0, 0, 0};
     if ((float)th > 1e-6f && s > 0.0) {
         const double k = th / s;
@@ -339,7 +416,13 @@ DVO_HD void se3_log_d(const double R[9], const double t[3], double xi[6])
     double v[3] = {t[0], t[1], t[2]};
     if ((float)wl > 1e-6f) {
         const double half = 0.5 * wl;
-        const double coef = (1.0 - (wl * cos(half)) / (2.0 * sin(half))) / wl2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        double sh, ch;
+        sincos_dev(half, sh, ch);
+#else
+        const double sh = sin(half), ch = cos(half);
+#endif
+        const double coef = (1.0 - (wl * ch) / (2.0 * sh)) / wl2;
         double wt[3], wwt[3];
         cross3(w, t, wt);
         cross3(w, wt, wwt);
@@ -374,9 +457,14 @@ DVO_HD void se3_exp_pair_d(const double xi[6], double Rp[9], double tp[3], doubl
     if (th < 2.220446049250313e-16) {
         Rp[0] = 1; Rp[1] = 0; Rp[2] = 0; Rp[3] = 0; Rp[4] = 1; Rp[5] = 0; Rp[6] = 0; Rp[7] = 0; Rp[8] = 1;
     } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos_dev(th, s, c);
+#else
         c = cos(th);
         s = sin(th);
-        const double c1 = 1.0 - c, rx = w[0] / th, ry = w[1] / th, rz = w[2] / th;
+#endif
+        const double ith = 1.0 / th;
+        const double c1 = 1.0 - c, rx = w[0] * ith, ry = w[1] * ith, rz = w[2] * ith;
         Rp[0] = c + c1 * rx * rx;      Rp[1] = c1 * rx * ry - s * rz; Rp[2] = c1 * rx * rz + s * ry;
         Rp[3] = c1 * rx * ry + s * rz; Rp[4] = c + c1 * ry * ry;      Rp[5] = c1 * ry * rz - s * rx;
         Rp[6] = c1 * rx * rz - s * ry; Rp[7] = c1 * ry * rz + s * rx; Rp[8] = c + c1 * rz * rz;
@@ -385,7 +473,8 @@ DVO_HD void se3_exp_pair_d(const double xi[6], double Rp[9], double tp[3], doubl
     Rm[3] = Rp[1]; Rm[4] = Rp[4]; Rm[5] = Rp[7];
     Rm[6] = Rp[2]; Rm[7] = Rp[5]; Rm[8] = Rp[8];
     if ((float)th > 1e-6f) {
-        const double A = (1.0 - c) / th2, B = (th - s) / (th2 * th);
+        const double ith = 1.0 / th, ith2 = ith * ith;
+        const double A = (1.0 - c) * ith2, B = (th - s) * (ith2 * ith);
         double wv[3], wwv[3];
         cross3(w, v, wv);
         cross3(w, wv, wwv);
@@ -519,7 +608,7 @@ DVO_HD void solve6(const double H[21], const double g[6], float x[6])
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = 0.0f;
     if (!(maxd > 0.0)) return;
-    double L[6][6], d[6], y[6], z[6];
+    double L[6][6], d[6], id[6], y[6], z[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -528,12 +617,14 @@ DVO_HD void solve6(const double H[21], const double g[6], float x[6])
         for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * d[k];
         ok = ok && (dj > 1e-12 * maxd);
         d[j] = dj;
+        const double inv = 1.0 / dj;   // ONE division per pivot (6 instead of 21): this runs on one lane, in series, after every iteration
+        id[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double v = H[tri(j, i)];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * d[k];
-            L[i][j] = v / dj;
+            L[i][j] = v * inv;
         }
     }
     if (ok) {
@@ -545,7 +636,7 @@ DVO_HD void solve6(const double H[21], const double g[6], float x[6])
             y[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) y[i] /= d[i];
+        for (int i = 0; i < 6; i++) y[i] *= id[i];
 #pragma unroll
         for (int i = 5; i >= 0; i--) {
             double v = y[i];

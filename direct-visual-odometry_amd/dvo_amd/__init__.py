@@ -96,7 +96,7 @@ EXPORTS = [
     "dvo_dataset_close", "dvo_op_ingest", "dvo_vo_odometrize_depth_raw", "dvo_op_undistort",
     "dvo_eval_ate", "dvo_eval_rpe", "dvo_pose_inverse", "dvo_traj_write_tum",
     "dvo_vo_save", "dvo_vo_load", "dvo_vo_set_history_limit", "dvo_op_visualize", "dvo_ppm_write",
-    "dvo_selftest_reciprocal", "dvo_selftest_sqrt", "dvo_selftest_division",
+    "dvo_selftest_reciprocal", "dvo_selftest_sqrt", "dvo_selftest_division", "dvo_selftest_trig",
 ]
 
 _lib = None
@@ -356,6 +356,13 @@ def selftest_reciprocal(dev=0):
     n = C.c_uint64(); bad = C.c_uint64(); first = C.c_uint32()
     _check(lib().dvo_selftest_reciprocal(dev, C.byref(n), C.byref(bad), C.byref(first)))
     return n.value, bad.value, first.value
+
+
+def selftest_trig(dev=0):
+    """The device's SE(3) sin / cos / atan2 kernels vs the math library on 2^24 arguments: largest relative differences (sin, cos, atan2)."""
+    a = C.c_double(); b = C.c_double(); c = C.c_double(); n = C.c_uint64()
+    _check(lib().dvo_selftest_trig(dev, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+    return a.value, b.value, c.value, n.value
 
 
 def selftest_sqrt(dev=0):

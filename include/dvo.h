@@ -342,6 +342,9 @@ int dvo_selftest_reciprocal(int device, uint64_t* fast_path_inputs, uint64_t* mi
  * (i < b_count), times ALL 2^23 mantissas of a in [1, 2); b_first = 0, b_stride = 1, b_count = 2^23 is every mantissa pair (minutes).
  * first_bad_pair = mb << 23 | ma.  mismatches must come back 0. */
 int dvo_selftest_sqrt(int device, uint64_t* inputs, uint64_t* mismatches, uint32_t* first_bad_bits);
+/* The double-precision sin / cos / atan2 kernels the device's SE(3) chain uses (polynomial kernels instead of the math library's
+ * general-purpose routines) against that library on 2^24 arguments of their domain: largest relative differences (expected < 1e-15). */
+int dvo_selftest_trig(int device, double* max_rel_sin, double* max_rel_cos, double* max_rel_atan2, uint64_t* samples);
 int dvo_selftest_division(int device, uint32_t b_first, uint32_t b_stride, uint32_t b_count, uint64_t* pairs, uint64_t* mismatches,
                           uint64_t* first_bad_pair);
 

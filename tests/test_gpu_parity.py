@@ -467,6 +467,16 @@ def test_device_reciprocal_is_ieee_for_every_float():
     assert n_fast == 2 * (200 * (1 << 23) + 1)   # both signs, exponents 2^-100 .. 2^100 (inclusive end point)
 
 
+def test_device_trig_kernels_match_the_math_library():
+    """The serial end of a Gauss-Newton step (exp / log of SE(3) in double, one lane) uses polynomial sin / cos / atan2 kernels on the
+    device.  Against the device math library over their whole fast domain (2^24 arguments: |x| from 1e-12 to 1e5 for sin / cos, the
+    (sqrt, trace) plane for atan2): within 1e-15 relative -- a few units in the last place of a double, far below the float rounding
+    every pose goes through."""
+    es, ec, ea, n = dvo.selftest_trig()
+    assert n == 1 << 24
+    assert es < 1e-15 and ec < 1e-15 and ea < 1e-15, (es, ec, ea)
+
+
 def test_device_short_division_and_sqrt_are_ieee():
     """k_regularize(_redecimate) runs its 8 divisions and 4 square roots per pixel as rcp / rsq + FMA corrections when every operand is a
     normal float in [2^-20, 2^20].  Bit-exact maps rest on those being THE correctly rounded results: the square root is compared with

@@ -26,11 +26,12 @@ print("iterations per level", lg["n_iter"])
 sol, wk = buf[0], buf[1]
 n = int((sol[:, 5] > 0).sum())
 us = lambda a, b: (b - a) / 100.0
+print("(solve = 6x6 solve + pose update + log / state stores: the two parts in brackets)")
 print("step level | solver: wait->slots  fence  sum  solve  publish | worker0: wake->args  gn_tile  drain  announce | step total (publish to publish)")
 for k in range(n):
     tot = us(sol[k - 1, 5], sol[k, 5]) if k > 0 else float("nan")
-    print("%3d   %d    | %8.2f %6.2f %5.2f %6.2f %7.2f | %8.2f %8.2f %6.2f %8.2f | %6.2f   (worker woke %.2f us after the publish)" % (
-        k, sol[k, 6], us(sol[k, 0], sol[k, 1]), us(sol[k, 1], sol[k, 2]), us(sol[k, 2], sol[k, 3]), us(sol[k, 3], sol[k, 4]), us(sol[k, 4], sol[k, 5]),
+    print("%3d   %d    | %8.2f %6.2f %5.2f %6.2f [%.2f %.2f] %7.2f | %8.2f %8.2f %6.2f %8.2f | %6.2f   (worker woke %.2f us after the publish)" % (
+        k, sol[k, 6], us(sol[k, 0], sol[k, 1]), us(sol[k, 1], sol[k, 2]), us(sol[k, 2], sol[k, 3]), us(sol[k, 3], sol[k, 4]), us(sol[k, 3], wk[k, 5]), us(wk[k, 5], wk[k, 6]), us(sol[k, 4], sol[k, 5]),
         us(wk[k, 0], wk[k, 3]), us(wk[k, 3], wk[k, 4]), us(wk[k, 4], wk[k, 1]), us(wk[k, 1], wk[k, 2]), tot,
         us(sol[k - 1, 5], wk[k, 0]) if k > 0 else float("nan")))
 vo.close()
