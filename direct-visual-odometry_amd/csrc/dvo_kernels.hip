@@ -1087,8 +1087,8 @@ __global__ void __launch_bounds__(256) k_track_gn_fused(GnArgs a, SolveArgs sa, 
 // `spin_limit` times without seeing its epoch marks the launch as given up and leaves; the others then run into the same limit.
 // The host sees the mark instead of the result tag and re-runs the frame with the launch-per-iteration schedule.
 // ------------------------------------------------------------------------------------------------
-template <int PPT, int G>
-__global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
+template <int PPT, int G, bool MONO>   // MONO: with the mono handle's keyframe decision as the tail (its own instance: the tail's two
+__global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // exponentials and logarithm otherwise weigh on the sensor-depth handle's solver)
 {
     __shared__ GnTileLds<PPT> lds;
     __shared__ double tot[32];
@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
                         for (int i = 0; i < 16; i++) p.T_out[i] = T[i];
                         float fxw[6], Tw[16];
                         int need = 0;
-                        if (p.mono.enabled) {   // a mono handle: Frame::updateXi, needNewFrame and exp(xi) here, not in a launch of their own
+                        if (MONO && p.mono.enabled) {   // a mono handle: Frame::updateXi, needNewFrame and exp(xi) here, not in a launch of their own
                             MonoSeq& m = *p.mono.meta;
                             for (int i = 0; i < 6; i++) m.ref_xi[i] = p.mono.ref_xi[i];
                             m.ref_id = p.mono.ref_id; m.n_total = p.mono.n_total;
@@ -1247,7 +1247,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)
                         if (p.host_result) {
                             for (int i = 0; i < 6; i++) p.host_result[i] = xi[i];
                             for (int i = 0; i < 16; i++) p.host_result[6 + i] = T[i];
-                            if (p.mono.enabled) {
+                            if (MONO && p.mono.enabled) {
                                 for (int i = 0; i < 6; i++) p.host_result[24 + i] = fxw[i];
                                 for (int i = 0; i < 16; i++) p.host_result[30 + i] = Tw[i];
                                 reinterpret_cast<int*>(p.host_result)[46] = need;
@@ -1768,9 +1768,9 @@ int track_persist_max_grid(int ppt, int group, int* out)
     int per_cu = 0, dev = 0;
     const int key = ppt * 10 + group;
     hipError_t e = hipErrorInvalidValue;
-    if (key == 11) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<1, 1>, 256, 0);
-    else if (key == 22) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<2, 2>, 256, 0);
-    else if (key == 42) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<4, 4>, 256, 0);
+    if (key == 11) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<1, 1, true>, 256, 0);   // (the instance with more registers)
+    else if (key == 22) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<2, 2, true>, 256, 0);
+    else if (key == 42) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_persist<4, 4, true>, 256, 0);
     if (e != hipSuccess) return DVO_ERR_HIP;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DVO_ERR_HIP;
@@ -1784,9 +1784,16 @@ bool launch_track_persist(const PersistArgs& p, int ppt, int group, int grid, hi
     if (grid < 1) return false;
     // (the gather group only sets how many pixels' gathers are in flight together, never a result: this kernel runs one wave per SIMD
     //  whatever it does, so it takes all of a thread's pixels at once)
-    if (key == 11) hipLaunchKernelGGL((k_track_persist<1, 1>), dim3(grid), dim3(256), 0, s, p);
-    else if (key == 22) hipLaunchKernelGGL((k_track_persist<2, 2>), dim3(grid), dim3(256), 0, s, p);
-    else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 4>), dim3(grid), dim3(256), 0, s, p);
+    if (p.mono.enabled) {
+        if (key == 11) hipLaunchKernelGGL((k_track_persist<1, 1, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (key == 22) hipLaunchKernelGGL((k_track_persist<2, 2, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 4, true>), dim3(grid), dim3(256), 0, s, p);
+        else return false;
+        return true;
+    }
+    if (key == 11) hipLaunchKernelGGL((k_track_persist<1, 1, false>), dim3(grid), dim3(256), 0, s, p);
+    else if (key == 22) hipLaunchKernelGGL((k_track_persist<2, 2, false>), dim3(grid), dim3(256), 0, s, p);
+    else if (key == 42) hipLaunchKernelGGL((k_track_persist<4, 4, false>), dim3(grid), dim3(256), 0, s, p);
     else return false;
     return true;
 }
