@@ -510,6 +510,7 @@ int Tracker::track(const FrameSet& obj, const FrameSet& ref, hipStream_t s)
             if (!persist_dbg.p) { DVO_TRY(persist_dbg.alloc(2 * 64 * 8 * sizeof(long long))); }
             DVO_HIP(hipMemsetAsync(persist_dbg.p, 0, persist_dbg.bytes, s));
             pa.dbg = persist_dbg.as<long long>();
+            pa.dbg_worker = atoi(getenv("DVO_PERSIST_TIMELINE"));
         }
         if (launch_track_persist(pa, ppt[0], group[0], persist_grid, s)) {
             persist_used = true;

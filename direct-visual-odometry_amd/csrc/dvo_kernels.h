@@ -142,6 +142,7 @@ struct PersistArgs {
     PersistMono mono;
     int host_tag;          // unique per launch: also the base of this launch's epoch numbers
     int spin_limit;        // polls of the epoch word before a workgroup gives up (every wait in the kernel is bounded)
+    int dbg_worker;        // which tile worker leaves the stamps (DVO_PERSIST_TIMELINE=<index>; 0 owns a corner tile of every level)
     long long* dbg;        // optional [2][64][8] wall-clock stamps (100 MHz) of the solver and of worker 0 per step (tools/persist_timeline.py)
 };
 bool track_persist_available(int ppt, int group);

@@ -424,6 +424,48 @@ __device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, 
     valid = ((int)is_invalid(I2) | (int)is_invalid(gx) | (int)is_invalid(gy)) == 0;  // bitwise on purpose: no short-circuit branches
 }
 
+// The generic sampler (dvo_math.h gn_sample: any position, any validity pattern -- the fill quirk of getSubpixel, INVALID gradients at the
+// image border and next to INVALID taps, clamping of missing taps to g00) with every tap it can touch requested UP FRONT from clamped
+// coordinates: one memory round trip instead of the five or six dependent ones of the branchy version, whose branches skip most of the
+// work for most border pixels and therefore win where throughput counts (k_track_gn: measured, see gn_tile).  Where LATENCY counts -- one
+// sequence, k_track_persist: every step waits for its slowest tile, and the slowest tiles are those with border pixels (5.3-6.1 us against
+// 2.85 us for an interior tile, profiles/r03_single_cpp_final.txt) -- this form is used.  The same float operations on the same values:
+// bit-identical results (the schedules are compared bit for bit in tests/test_gpu_parity.py).
+__device__ __forceinline__ bool gn_sample_patch(const float* __restrict__ img, const int w, const int h, const float d, const float u, const float v,
+                                                float& I2, float& gx, float& gy)
+{
+    I2 = kInvalid; gx = kInvalid; gy = kInvalid;
+    if (is_epsilon(d) || !coord_ok(u) || !coord_ok(v)) return false;   // transform.cpp:44; load_taps' first gate
+    const int x0 = (int)u, y0 = (int)v;
+    if (x0 < 0 || w <= x0 || y0 < 0 || h <= y0) return false;
+    const bool hasXm = x0 >= 1, inx = x0 + 1 < w, hasX2 = x0 + 2 < w, hasYm = y0 >= 1, iny = y0 + 1 < h, hasY2 = y0 + 2 < h;
+    const int xm = hasXm ? x0 - 1 : x0, x1 = inx ? x0 + 1 : x0, x2 = hasX2 ? x0 + 2 : x0;
+    const int rm = (hasYm ? y0 - 1 : y0) * w, r0 = y0 * w, r1 = (iny ? y0 + 1 : y0) * w, r2 = (hasY2 ? y0 + 2 : y0) * w;
+    const float Tm0 = img[rm + x0], Tm1 = img[rm + x1];
+    const float T0m = img[r0 + xm], T00 = img[r0 + x0], T01 = img[r0 + x1], T02 = img[r0 + x2];
+    const float T1m = img[r1 + xm], T10 = img[r1 + x0], T11 = img[r1 + x1], T12 = img[r1 + x2];
+    const float T20 = img[r2 + x0], T21 = img[r2 + x1];
+    const float hx = u - (float)x0, vy = v - (float)y0;
+    float g[4] = {T00, inx ? T01 : T00, iny ? T10 : T00, (inx && iny) ? T11 : T00};   // load_taps: a missing tap is g00
+    if (!fill_quirk(g)) return false;
+    I2 = blend4(g[0], g[1], g[2], g[3], hx, vy);
+    if (is_invalid(I2)) return false;
+    if (u < 0.0f || v < 0.0f || (float)w <= u || (float)h <= v) return false;       // optimize.cpp:52-56
+    // Convert::gradiate at the four corners (grad_x_at / grad_y_at): INVALID unless both neighbours exist and are valid
+    auto diff = [](bool exists, float a, float b) { return (exists && is_valid(a) && is_valid(b)) ? b - a : kInvalid; };
+    const float gx00 = diff(hasXm && inx, T0m, T01);
+    const float gx10 = inx ? diff(hasX2, T00, T02) : gx00;
+    const float gx01 = iny ? diff(hasXm && inx, T1m, T11) : gx00;
+    const float gx11 = (inx && iny) ? diff(hasX2, T10, T12) : gx00;
+    const float gy00 = diff(hasYm && iny, Tm0, T10);
+    const float gy10 = inx ? diff(hasYm && iny, Tm1, T11) : gy00;
+    const float gy01 = iny ? diff(hasY2, T00, T20) : gy00;
+    const float gy11 = (inx && iny) ? diff(hasY2, T01, T21) : gy00;
+    gx = blend4(gx00, gx10, gx01, gx11, hx, vy);
+    gy = blend4(gy00, gy10, gy01, gy11, hx, vy);
+    return !(is_invalid(gx) || is_invalid(gy));
+}
+
 // k_prep_ref: the per-pixel constant of a reference frame (all levels, one launch): wgt = step(level) / clamp(sigma) -- the
 // division of optimize.cpp:83-84, which does not depend on the pose, evaluated once per frame instead of once per Gauss-Newton
 // iteration.  (1 / depth, optimize.cpp:70-74, was a second such map in round 1: 4 B per pixel and iteration through HBM and the L1
@@ -453,7 +495,9 @@ struct GnTileLds {
 // consecutive raster pixels.  Used when the level width is a multiple of 64: only tiles on the image border then hold
 // deferred (border) pixels, a thread's pixels share their column (one int->float conversion and one (x - cx) for PPT
 // pixels) and there is no row-wrap arithmetic.
-template <int PPT, int G, bool MASK, bool T2D>
+// LAT: the deferred pixels take gn_sample_patch (one memory round trip) instead of the branchy generic sampler: for callers that wait for
+// the slowest tile of a single sequence (k_track_persist).
+template <int PPT, int G, bool MASK, bool T2D, bool LAT = false>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row);
 
@@ -487,7 +531,7 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
     clear_next();
 }
 
-template <int PPT, int G, bool MASK, bool T2D>
+template <int PPT, int G, bool MASK, bool T2D, bool LAT>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row)
 {
@@ -636,6 +680,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             const int i = slow_q[qw][e - qoff];  // < npix (only gated pixels are queued)
             int x, y;
             split_index(i, w, a.inv_w, x, y);
+            // (carrying d and I1 through LDS with the index instead of re-loading them: measured in the LAT form, no change)
             const float d = dep[i], I1 = obj[i], iz = recip_gated(dep[i], true), wg = wgp ? wgp[i] : a.wgt_const;
             float u, v;
             warp(pose, a.k, (float)x, (float)y, d, u, v);  // same operations on the same inputs as in the main loop
@@ -644,7 +689,8 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             // clamped coordinates -- one round trip, no divergent loads.  Slower by 20 % on the probe: the branches of the
             // memory version skip most of the work for most border pixels.)
             SlowSample ss;
-            ss.ok = gn_sample(GlobalImg{refp, w, h}, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
+            if constexpr (LAT) ss.ok = gn_sample_patch(refp, w, h, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
+            else ss.ok = gn_sample(GlobalImg{refp, w, h}, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
             const bool ok = ss.ok != 0;
             float J[6], r, rw;
             gn_jacobian_pre(a.k, x, y, d, iz, wg, ss.gx, ss.gy, I1, ss.I2, J, r, rw);
@@ -1129,7 +1175,7 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
                 line_s[threadIdx.x] = v;
             }
             __syncthreads();
-            const bool stamp = p.dbg && me == 0 && threadIdx.x == 0 && step < 64;
+            const bool stamp = p.dbg && me == p.dbg_worker && threadIdx.x == 0 && step < 64;
             if (stamp) p.dbg[(64 + step) * 8 + 0] = wall_clock64();   // line seen
             const int status = line_s[2];
             if (status != 0) {
@@ -1155,10 +1201,10 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
             for (int t = me; t < L.blk_count; t += n_work) {
                 float* row = p.partials + (size_t)(L.blk_first + t) * 32;
                 if constexpr (PPT == 4) {
-                    if (L.t2d) gn_tile<PPT, G, false, true>(a, pose, 0, L.blk_first + t, lds, row);
-                    else gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
+                    if (L.t2d) gn_tile<PPT, G, false, true, true>(a, pose, 0, L.blk_first + t, lds, row);
+                    else gn_tile<PPT, G, false, false, true>(a, pose, 0, L.blk_first + t, lds, row);
                 } else {
-                    gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
+                    gn_tile<PPT, G, false, false, true>(a, pose, 0, L.blk_first + t, lds, row);
                 }
                 __syncthreads();   // (the next tile reuses the LDS scratch)
             }

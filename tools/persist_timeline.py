@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Where one k_track_persist iteration goes: wall-clock stamps (100 MHz) the solver workgroup and worker 0 leave per step when
-DVO_PERSIST_TIMELINE=1.  python tools/persist_timeline.py"""
+DVO_PERSIST_TIMELINE=<worker index>.  python tools/persist_timeline.py [worker index]"""
 import ctypes as C
 import os
 import sys
 
-os.environ["DVO_PERSIST_TIMELINE"] = "1"
+os.environ["DVO_PERSIST_TIMELINE"] = sys.argv[1] if len(sys.argv) > 1 else "0"   # index of the tile worker that leaves the stamps (0: a corner tile)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "direct-visual-odometry_amd"))
 import numpy as np
