@@ -795,6 +795,7 @@ VisualOdometry::~VisualOdometry()
     for (int i = 0; i < 3; i++)
         if (uevent[i]) (void)hipEventDestroy(uevent[i]);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (h_tables) { if (stream) (void)hipStreamSynchronize(stream); (void)hipHostFree(h_tables); }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -873,6 +874,36 @@ int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
     return DVO_OK;
 }
 
+int VisualOdometry::refresh_history_tables()
+{  // device copies of FrameHistory's poses and top-level gray pointers (+ room for the age table): current after this call
+    const int T = geoM.top();
+    const int n_hist = (int)hist.size();
+    if (hist_table_version == hist_version && hist_table_n == n_hist) return DVO_OK;
+    // Staged in PINNED host memory, copied without a synchronisation: the staging block is rewritten only by a later call of this
+    // function, i.e. in a later frame, and every frame waits for its tracking result, which is stream-ordered after these copies.
+    const size_t xi_bytes = sizeof(float) * 6 * (size_t)n_hist, gt_bytes = sizeof(float*) * (size_t)n_hist;
+    if (h_tables_bytes < xi_bytes + gt_bytes) {
+        DVO_HIP(hipStreamSynchronize(stream));   // (the old tables / staging block may still be read by queued work)
+        if (h_tables) DVO_HIP(hipHostFree(h_tables));
+        h_tables = nullptr;
+        h_tables_bytes = 2 * (xi_bytes + gt_bytes);
+        DVO_HIP(hipHostMalloc(&h_tables, h_tables_bytes, hipHostMallocDefault));
+        DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
+        DVO_TRY(hist_xi_dev.alloc(2 * xi_bytes));
+        DVO_TRY(gray_tab_dev.alloc(2 * gt_bytes));
+    }
+    float* hx = static_cast<float*>(h_tables);
+    const float** gt = reinterpret_cast<const float**>(static_cast<char*>(h_tables) + xi_bytes);   // (xi_bytes is a multiple of 8)
+    for (int i = 0; i < n_hist; i++) {
+        memcpy(hx + (size_t)i * 6, hist[i]->xi, 6 * sizeof(float));
+        gt[i] = hist[i]->fs.gray[T];
+    }
+    DVO_HIP(hipMemcpyAsync(hist_xi_dev.p, hx, xi_bytes, hipMemcpyHostToDevice, stream));
+    DVO_HIP(hipMemcpyAsync(gray_tab_dev.p, gt, gt_bytes, hipMemcpyHostToDevice, stream));
+    hist_table_n = n_hist; hist_table_version = hist_version;
+    return DVO_OK;
+}
+
 int VisualOdometry::map_update(Keyframe& obj)
 {  // Mapper::update, mapper.cpp:76-137
     Keyframe& ref = *hist.back();
@@ -881,29 +912,13 @@ int VisualOdometry::map_update(Keyframe& obj)
     // mapper.cpp:107: r_xi = concatenate(obj.xi, -born.xi), once per keyframe, on the device (k_age_table).  The keyframes' poses and
     // top-level gray pointers only change when FrameHistory does (a keyframe pushed, dropped or loaded): the device copies are
     // refreshed then (hist_version), not on every frame -- two uploads and a stream synchronisation less per tracked frame.
-    if (hist_table_version != hist_version || hist_table_n != n_hist) {
-        hist_hx.resize((size_t)n_hist * 6);
-        hist_gt.resize((size_t)n_hist);
-        for (int i = 0; i < n_hist; i++) {
-            memcpy(&hist_hx[(size_t)i * 6], hist[i]->xi, 6 * sizeof(float));
-            hist_gt[i] = hist[i]->fs.gray[T];
-        }
-        if (ages.bytes < sizeof(AgeEntry) * (size_t)n_hist) {
-            DVO_HIP(hipStreamSynchronize(stream));   // (the old tables may still be read by queued kernels)
-            DVO_TRY(ages.alloc(sizeof(AgeEntry) * (size_t)n_hist * 2));
-            DVO_TRY(hist_xi_dev.alloc(sizeof(float) * 6 * (size_t)n_hist * 2));
-            DVO_TRY(gray_tab_dev.alloc(sizeof(float*) * (size_t)n_hist * 2));
-        }
-        DVO_HIP(hipMemcpyAsync(hist_xi_dev.p, hist_hx.data(), hist_hx.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-        DVO_HIP(hipMemcpyAsync(gray_tab_dev.p, hist_gt.data(), hist_gt.size() * sizeof(float*), hipMemcpyHostToDevice, stream));
-        DVO_HIP(hipStreamSynchronize(stream));       // hist_hx / hist_gt are pageable host memory: done before they can change again
-        hist_table_n = n_hist; hist_table_version = hist_version;
-    }
+    DVO_TRY(refresh_history_tables());
     AgeTableArgs ta;
     ta.meta = meta_dev.as<MonoSeq>(); ta.hist_xi = hist_xi_dev.as<float>(); ta.ages = ages.as<AgeEntry>();
     ta.n_seq = 1; ta.R = n_hist; ta.n_hist = n_hist;
     ta.zero_word = valid_dev.as<int>();   // mapper.cpp:136's count of this update (read back when dvo_vo_last_valid_updates asks)
-    launch_age_table(ta, stream);
+    if (!age_table_done) launch_age_table(ta, stream);   // (done: the tail of k_track_persist computed it, odometrize())
+    age_table_done = false;
     UpdateArgs a;
     memset(&a, 0, sizeof a);
     a.ref_depth = ref.fs.depth[T]; a.ref_sigma = ref.fs.sigma[T]; a.ref_age = ref.age.as<float>();
@@ -1020,6 +1035,10 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
         pm.ref_id = ref.id; pm.n_total = (int)hist.size();
         pm.frame_id = frame.id; pm.max_frames = cfg.keyframe_max_frames; pm.min_translation = cfg.keyframe_min_translation;
         pm.enabled = 1;
+        // ... and Mapper::update's per-keyframe relative poses (k_age_table), which only need the frame's pose and FrameHistory's
+        DVO_TRY(refresh_history_tables());
+        pm.hist_xi = hist_xi_dev.as<float>(); pm.ages = ages.as<AgeEntry>(); pm.n_hist = (int)hist.size();
+        pm.zero_word = valid_dev.as<int>();
     }
     DVO_TRY(trkM.track(frame.fs, ref.fs, stream));  // system.hpp:57
     bool decided = false;
@@ -1032,6 +1051,7 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
             memcpy(h_meta.T_world, trkM.h_result + 30, sizeof h_meta.T_world);
             h_meta.need = reinterpret_cast<const int*>(trkM.h_result)[46];
             decided = true;
+            age_table_done = h_meta.need == 0;   // (the same launch computed the age table for the update that follows)
         }
     }
     if (!decided) {

@@ -219,7 +219,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     bool valid_updates_pending = false;                // last_valid_updates is stale: the count of the last map_update is still on the device
     int fetch_valid_updates();
     // device copies of FrameHistory's poses / gray pointers (k_age_table, k_depth_update): refreshed when the history changes
-    std::vector<float> hist_hx; std::vector<const float*> hist_gt;
+
     int hist_table_n = -1;
     unsigned long long hist_version = 0, hist_table_version = ~0ull;   // hist_version: bumped wherever `hist` changes
     float last_xi[6] = {0}, last_rel[6] = {0};
@@ -244,6 +244,10 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int init_keyframe(const float* gray, const float* depth, const float* sigma);
     int map_propagate(Keyframe& frame, const Keyframe& ref);
     int map_update(Keyframe& obj);
+    int refresh_history_tables();
+    void* h_tables = nullptr;      // pinned staging of the history tables
+    size_t h_tables_bytes = 0;
+    bool age_table_done = false;   // this frame's age table came out of k_track_persist's tail
     int map_regularize(Keyframe& kf);
 };
 

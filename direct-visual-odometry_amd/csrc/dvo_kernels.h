@@ -119,6 +119,7 @@ struct PersistLevel {
     int blk_first, blk_count, t_shift, x_org, y_org, tiles_x, t2d, level_pixels;
 };
 struct MonoSeq;
+struct AgeEntry;
 struct PersistMono {       // optional tail of k_track_persist for a mono dvo_vo handle: what k_mono_decide does, by the solver's thread, in the
     MonoSeq* meta;         // same launch -- the pose, the keyframe decision and the world pose reach the host with the tracker's tag
     float ref_xi[6];       // the reference keyframe (the host keeps FrameHistory): MonoRef's fields
@@ -126,6 +127,11 @@ struct PersistMono {       // optional tail of k_track_persist for a mono dvo_vo
     int frame_id, max_frames;
     float min_translation;
     int enabled;
+    // ... and k_age_table's (the per-keyframe relative poses of Mapper::update) when the frame is not a keyframe, by the solver's workgroup:
+    const float* hist_xi;  // [n_hist][6], device copy of FrameHistory's poses (current: the host refreshed it before the launch); nullptr: not here
+    AgeEntry* ages;        // [n_hist]
+    int n_hist;
+    int* zero_word;        // the valid-update counter of the depth update that follows (cleared here)
 };
 struct PersistArgs {
     PersistLevel lv[DVO_MAX_LEVELS];
@@ -247,6 +253,18 @@ struct AgeEntry {      // one keyframe as seen from the current frame (Mapper::u
     float tneg[3];     // -r_xi[0:3] (twist part; implement.cpp:56)
     int   slot;        // where the born keyframe's top-level gray lives: ring slot (batch) or history index (single handle)
 };
+
+// One entry of the age table (Mapper::update, mapper.cpp:99-107, hoisted out of the pixel loop): r_xi = concatenate(obj.xi, -born.xi), the
+// pose exp(-r_xi) the epipolar search warps with and -r_xi's translation (implement.cpp:56).  Shared by k_age_table and k_track_persist's tail.
+__device__ __forceinline__ void age_entry_one(const float frame_xi[6], const float* born_xi, int slot, AgeEntry& e)
+{
+    float ox[6], nb[6], r_xi[6];
+    for (int k = 0; k < 6; k++) { ox[k] = frame_xi[k]; nb[k] = -born_xi[k]; }
+    se3_concatenate_f(ox, nb, r_xi);
+    pose_from_xi(r_xi, -1.0f, e.pose);
+    for (int k = 0; k < 3; k++) e.tneg[k] = -r_xi[k];
+    e.slot = slot;
+}
 
 struct AgeTableArgs {  // k_age_table: AgeEntry of every retained keyframe, once per frame and sequence (never per pixel)
     const MonoSeq* meta;

@@ -1140,6 +1140,8 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
     __shared__ double tot[32];
     __shared__ double part[DVO_SOLVE_GROUPS][32];
     __shared__ int line_s[16];   // the control line as this workgroup last read / is about to write it
+    __shared__ float mono_fx_s[6];   // (MONO) the frame's pose and keyframe flag, from the solver's thread to the age-table tail
+    __shared__ int mono_need_s;
     __shared__ int gave_up_s;
     // Workgroup 0 only solves; workgroups 1 .. grid-1 evaluate tiles.  Nobody takes a contended atomic: a worker announces its tiles of
     // step s by storing (epoch0 + s + 1) into its OWN slot of `arrive`, the solver polls the slots (one lane each); the solver
@@ -1289,6 +1291,8 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
                             for (int i = 0; i < 6; i++) m.ref_xi[i] = p.mono.ref_xi[i];
                             m.ref_id = p.mono.ref_id; m.n_total = p.mono.n_total;
                             need = mono_decide_one(m, xi, p.mono.frame_id, p.mono.min_translation, p.mono.max_frames, fxw, Tw);
+                            for (int i = 0; i < 6; i++) mono_fx_s[i] = fxw[i];
+                            mono_need_s = need;
                         }
                         if (p.host_result) {
                             for (int i = 0; i < 6; i++) p.host_result[i] = xi[i];
@@ -1321,7 +1325,23 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
         if (stamp) p.dbg[step * 8 + 5] = wall_clock64();   // published
         const int st_now = line_s[2], nl_now = line_s[1];
         __syncthreads();
-        if (st_now != 0) break;
+        if (st_now != 0) {
+            if constexpr (MONO) {
+                // The frame is tracked and (thread 0, above) decided.  Not a keyframe: Mapper::update follows, and its per-keyframe
+                // relative poses are this workgroup's last job -- one thread per keyframe of FrameHistory -- instead of a launch of their own.
+                if (st_now == 1 && p.mono.enabled && p.mono.hist_xi && mono_need_s == 0) {
+                    float fxi[6];
+                    for (int k = 0; k < 6; k++) fxi[k] = mono_fx_s[k];   // (written by thread 0 before the barriers above)
+                    for (int i = (int)threadIdx.x; i < p.mono.n_hist; i += 256) {
+                        AgeEntry e;
+                        age_entry_one(fxi, p.mono.hist_xi + (size_t)i * 6, i, e);
+                        p.mono.ages[i] = e;
+                    }
+                    if (threadIdx.x == 0 && p.mono.zero_word) *p.mono.zero_word = 0;
+                }
+            }
+            break;
+        }
         first = (nl_now != level) ? 1 : 0;
         level = nl_now;
         step++;

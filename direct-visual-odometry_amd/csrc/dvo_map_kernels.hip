@@ -102,13 +102,8 @@ __global__ void __launch_bounds__(64) k_age_table(AgeTableArgs a)
         slot = (m.n_total - n_hist + i) % a.R;
     }
     if (i >= n_hist) return;
-    float ox[6], nb[6], r_xi[6];
-    for (int k = 0; k < 6; k++) { ox[k] = m.frame_xi[k]; nb[k] = -a.hist_xi[((size_t)seq * a.R + slot) * 6 + k]; }
-    se3_concatenate_f(ox, nb, r_xi);
     AgeEntry e;
-    pose_from_xi(r_xi, -1.0f, e.pose);
-    for (int k = 0; k < 3; k++) e.tneg[k] = -r_xi[k];
-    e.slot = slot;
+    age_entry_one(m.frame_xi, a.hist_xi + ((size_t)seq * a.R + slot) * 6, slot, e);
     a.ages[(size_t)seq * a.R + i] = e;
 }
 
