@@ -795,6 +795,7 @@ VisualOdometry::~VisualOdometry()
     for (int i = 0; i < 3; i++)
         if (uevent[i]) (void)hipEventDestroy(uevent[i]);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (h_stage) { if (stream) (void)hipStreamSynchronize(stream); (void)hipHostFree(h_stage); }
     if (h_tables) { if (stream) (void)hipStreamSynchronize(stream); (void)hipHostFree(h_tables); }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -872,6 +873,22 @@ int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
     // (Frame::updateDepthSigmaAge, frame.cpp:47-54, re-decimates both maps here; Mapper::regularize and Frame::updateDepth follow at
     //  once, mapper.cpp:26, and decimate the depth again: map_regularize() derives every level of both pyramids in its one pass)
     return DVO_OK;
+}
+
+int VisualOdometry::alloc_stage()
+{  // pinned, device-mapped: [colour / gray rows, up to 4 bytes per pixel][16-bit depth rows]
+    if (h_stage) return DVO_OK;
+    DVO_HIP(hipHostMalloc(&h_stage, (size_t)w * h * 6, hipHostMallocMapped));
+    DVO_HIP(hipHostGetDevicePointer(&d_stage, h_stage, 0));
+    return DVO_OK;
+}
+
+static void stage_rows_host(void* dst, const void* src, size_t row_bytes, int rows, int culls, bool decimate)
+{  // the rows the pyramid keeps (every 2^culls-th) -- or all of them -- packed
+    if (!decimate || culls <= 0) { memcpy(dst, src, row_bytes * (size_t)rows); return; }
+    const int kept = rows >> culls;
+    for (int r = 0; r < kept; r++)
+        memcpy(static_cast<char*>(dst) + (size_t)r * row_bytes, static_cast<const char*>(src) + ((size_t)r << culls) * row_bytes, row_bytes);
 }
 
 int VisualOdometry::refresh_history_tables()
@@ -978,25 +995,40 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     // still queued on `stream`, and a copy queued behind them would wait for them although it touches nothing they do -- the staging
     // buffers were last read by the previous frame's pyramid, which that call waited for (the pose read-back).  The pyramid waits
     // for the copy (event), then everything is in stream order again.
-    DVO_TRY(upload_streams());
-    hipStream_t up = ustream[1];
+    // (r3, later) ... or no copy at all: the mono pyramid keeps one row in four (cull 2), 77-307 KB of the frame.  The caller's thread
+    // copies those rows into a pinned, device-mapped staging block -- what the runtime's own path for pageable memory starts with -- and
+    // k_pyramid reads them from there over the host link; the runtime's copy (API + DMA + 22-37 us until the dependent kernel starts,
+    // profiles/r03_mono_single_trace_final.txt) drops out.  The block was last read by the previous frame's pyramid, which that call waited
+    // for.  DVO_MONO_STAGE=0: the copy on the side stream, as before.
+    static const bool stage_rows = getenv("DVO_MONO_STAGE") == nullptr || atoi(getenv("DVO_MONO_STAGE")) != 0;
     FrameInput fin;
-    if (raw) {
-        const size_t px = (size_t)w * h;
-        if (raw_rgb.bytes < px * 4) {
-            DVO_HIP(hipStreamSynchronize(stream));
-            DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2));
+    fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps are copied / cross PCIe
+    const size_t row_bytes = raw ? (size_t)w * raw_channels : (size_t)w * sizeof(float);
+    if (stage_rows) {
+        if (!h_stage) {
+            DVO_TRY(alloc_stage());
         }
-        fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps cross PCIe
-        DVO_TRY(upload_rows(raw_rgb.p, raw, (size_t)w * raw_channels, h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
-        fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
+        stage_rows_host(h_stage, raw ? static_cast<const void*>(raw) : static_cast<const void*>(gray), row_bytes, h, geoM.culls, fin.rows_decimated);
+        if (raw) { fin.rgb = static_cast<const uint8_t*>(d_stage); fin.channels = raw_channels; }
+        else fin.gray = static_cast<const float*>(d_stage);
     } else {
-        fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);
-        DVO_TRY(upload_rows(in_gray.p, gray, (size_t)w * sizeof(float), h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
-        fin.gray = in_gray.as<float>();
+        DVO_TRY(upload_streams());
+        hipStream_t up = ustream[1];
+        if (raw) {
+            const size_t px = (size_t)w * h;
+            if (raw_rgb.bytes < px * 4) {
+                DVO_HIP(hipStreamSynchronize(stream));
+                DVO_TRY(raw_rgb.alloc(px * 4)); DVO_TRY(raw_depth.alloc(px * 2));
+            }
+            DVO_TRY(upload_rows(raw_rgb.p, raw, row_bytes, h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
+            fin.rgb = raw_rgb.as<uint8_t>(); fin.channels = raw_channels;
+        } else {
+            DVO_TRY(upload_rows(in_gray.p, gray, row_bytes, h, 1, geoM.culls, fin.rows_decimated, up, nullptr));
+            fin.gray = in_gray.as<float>();
+        }
+        DVO_HIP(hipEventRecord(uevent[2], up));
+        DVO_HIP(hipStreamWaitEvent(stream, uevent[2], 0));
     }
-    DVO_HIP(hipEventRecord(uevent[2], up));
-    DVO_HIP(hipStreamWaitEvent(stream, uevent[2], 0));
     if (!scratch) { scratch = std::make_unique<Keyframe>(); DVO_TRY(scratch->alloc(geoM, cfg, &kf_pool)); }
     Keyframe& frame = *scratch;
     frame.id = ++latest_id;
@@ -1132,6 +1164,18 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     in.rows_decimated = decimate_host_rows && can_decimate_rows(geoD);   // only the rows the pyramid keeps cross PCIe
     DVO_TRY(upload_streams());
     if (side_built) { DVO_HIP(hipStreamWaitEvent(stream, uevent[1], 0)); side_built = false; }   // a float-map frame's depth pyramid may still be building: it is this call's reference
+    // The kept rows of both frames (0.46 MB of 0.92 at cull 1) are staged by the caller's thread in pinned, device-mapped memory and read
+    // from there by k_pyramid_raw4 -- no runtime copy (as in the mono loop; DVO_RAW_STAGE=0: two copies, the depth on the side stream).
+    static const bool stage_rows = getenv("DVO_RAW_STAGE") == nullptr || atoi(getenv("DVO_RAW_STAGE")) != 0;
+    if (stage_rows) {
+        DVO_TRY(alloc_stage());
+        char* hs = static_cast<char*>(h_stage);
+        stage_rows_host(hs, rgb, (size_t)w * channels, h, geoD.culls, in.rows_decimated);
+        stage_rows_host(hs + (size_t)w * h * 4, depth16, (size_t)w * 2, h, geoD.culls, in.rows_decimated);
+        in.rgb = static_cast<const uint8_t*>(d_stage); in.channels = channels;
+        in.depth16 = reinterpret_cast<const uint16_t*>(static_cast<const char*>(d_stage) + (size_t)w * h * 4); in.depth_scale = depth_scale;
+        return odometrize_depth_staged(T_rel, &in);
+    }
     DVO_TRY(upload_rows(raw_depth.p, depth16, (size_t)w * 2, h, 1, geoD.culls, in.rows_decimated, ustream[0], nullptr));
     DVO_HIP(hipEventRecord(uevent[0], ustream[0]));
     DVO_TRY(upload_rows(raw_rgb.p, rgb, (size_t)w * channels, h, 1, geoD.culls, in.rows_decimated, stream, nullptr));

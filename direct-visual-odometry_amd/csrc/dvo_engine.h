@@ -245,6 +245,9 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int map_propagate(Keyframe& frame, const Keyframe& ref);
     int map_update(Keyframe& obj);
     int refresh_history_tables();
+    int alloc_stage();
+    void* h_stage = nullptr;       // pinned, device-mapped staging of a mono frame's kept rows (k_pyramid reads it through d_stage)
+    void* d_stage = nullptr;
     void* h_tables = nullptr;      // pinned staging of the history tables
     size_t h_tables_bytes = 0;
     bool age_table_done = false;   // this frame's age table came out of k_track_persist's tail
