@@ -812,6 +812,8 @@ int VisualOdometry::init(const float K9[9], int width, int height, const dvo_con
     DVO_TRY(select_device(device));
     if (cfg.stream) stream = (hipStream_t)cfg.stream;
     else { DVO_HIP(hipStreamCreate(&stream)); own_stream = true; }
+    stage_mono_rows = getenv("DVO_MONO_STAGE") == nullptr || atoi(getenv("DVO_MONO_STAGE")) != 0;   // (read per handle: tests compare both paths)
+    stage_raw_rows = getenv("DVO_RAW_STAGE") == nullptr || atoi(getenv("DVO_RAW_STAGE")) != 0;
     DVO_TRY(make_geometry(K, w, h, 3, 2, geoM));  // system.hpp:47
     DVO_TRY(make_geometry(K, w, h, 4, 1, geoD));  // system.hpp:82
     const size_t n = (size_t)w * h * sizeof(float);
@@ -1000,7 +1002,7 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     // k_pyramid reads them from there over the host link; the runtime's copy (API + DMA + 22-37 us until the dependent kernel starts,
     // profiles/r03_mono_single_trace_final.txt) drops out.  The block was last read by the previous frame's pyramid, which that call waited
     // for.  DVO_MONO_STAGE=0: the copy on the side stream, as before.
-    static const bool stage_rows = getenv("DVO_MONO_STAGE") == nullptr || atoi(getenv("DVO_MONO_STAGE")) != 0;
+    const bool stage_rows = stage_mono_rows;
     FrameInput fin;
     fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps are copied / cross PCIe
     const size_t row_bytes = raw ? (size_t)w * raw_channels : (size_t)w * sizeof(float);
@@ -1166,8 +1168,7 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     if (side_built) { DVO_HIP(hipStreamWaitEvent(stream, uevent[1], 0)); side_built = false; }   // a float-map frame's depth pyramid may still be building: it is this call's reference
     // The kept rows of both frames (0.46 MB of 0.92 at cull 1) are staged by the caller's thread in pinned, device-mapped memory and read
     // from there by k_pyramid_raw4 -- no runtime copy (as in the mono loop; DVO_RAW_STAGE=0: two copies, the depth on the side stream).
-    static const bool stage_rows = getenv("DVO_RAW_STAGE") == nullptr || atoi(getenv("DVO_RAW_STAGE")) != 0;
-    if (stage_rows) {
+    if (stage_raw_rows) {
         DVO_TRY(alloc_stage());
         char* hs = static_cast<char*>(h_stage);
         stage_rows_host(hs, rgb, (size_t)w * channels, h, geoD.culls, in.rows_decimated);

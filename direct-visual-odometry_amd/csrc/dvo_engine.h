@@ -246,6 +246,7 @@ struct VisualOdometry {  // System::VisualOdometry, system.hpp:12-104
     int map_update(Keyframe& obj);
     int refresh_history_tables();
     int alloc_stage();
+    bool stage_mono_rows = true, stage_raw_rows = true;   // frames reach the pyramid kernel through the staging block (DVO_MONO_STAGE / DVO_RAW_STAGE = 0: runtime copies)
     void* h_stage = nullptr;       // pinned, device-mapped staging of a mono frame's kept rows (k_pyramid reads it through d_stage)
     void* d_stage = nullptr;
     void* h_tables = nullptr;      // pinned staging of the history tables

@@ -778,6 +778,36 @@ def test_mono_handle_schedules_give_the_same_bits(monkeypatch):
                 np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32), err_msg="%s frame %d map %d" % (name, i, k))
 
 
+def test_host_frame_staging_paths_give_the_same_bits(monkeypatch):
+    """A mono frame and a raw sensor-depth frame reach the pyramid kernel either through a pinned, device-mapped staging block the
+    caller's thread fills (default) or through the runtime's copies (DVO_MONO_STAGE=0 / DVO_RAW_STAGE=0): same poses, same maps."""
+    g, d, _, _ = frames(6, seed=42, sigma=0.1)
+    g8 = [np.clip(np.rint(x * 255), 0, 255).astype(np.uint8) for x in g]
+    d16 = [np.clip(np.rint(x * 5000), 0, 65535).astype(np.uint16) for x in d]
+    d0 = d[0][::4, ::4].copy()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DVO_MONO_STAGE", mode)
+        monkeypatch.setenv("DVO_RAW_STAGE", mode)
+        out = []
+        vo = dvo.VisualOdometry(K640, 640, 480, cfg=dvo.default_config(rng_seed=3))
+        vo.setInitialDepth(d0, np.full_like(d0, 0.5))
+        for i in range(6):
+            T, key = vo.odometrize(g[i]) if i % 2 == 0 else vo.odometrizeRaw(g8[i])
+            out.append(T.copy())
+        out.append(vo.keyframe(vo.keyframeCount() - 1)["depth"].copy())
+        vo.close()
+        vo = dvo.VisualOdometry(K640, 640, 480)
+        for i in range(4):
+            out.append(vo.odometrizeUsingDepthRaw(g8[i], d16[i]).copy())
+        vo.close()
+        res[mode] = out
+    monkeypatch.delenv("DVO_MONO_STAGE", raising=False)
+    monkeypatch.delenv("DVO_RAW_STAGE", raising=False)
+    for a, b in zip(res["1"], res["0"]):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_single_handle_one_launch_schedule_edge_cases():
     """k_track_persist (one launch per odometrizeUsingDepth call) where its control flow is unusual: a fixed iteration count (the
     level never 'stops' by a threshold), a reference without any usable depth (every step has zero contributing pixels: residual -1,
