@@ -877,6 +877,8 @@ int VisualOdometry::map_propagate(Keyframe& frame, const Keyframe& ref)
     return DVO_OK;
 }
 
+static const size_t kStageLimitBytes = 512 * 1024;
+
 int VisualOdometry::alloc_stage()
 {  // pinned, device-mapped: [colour / gray rows, up to 4 bytes per pixel][16-bit depth rows]
     if (h_stage) return DVO_OK;
@@ -1002,10 +1004,11 @@ int VisualOdometry::odometrize(const float* gray, float T_world[16], int* is_key
     // k_pyramid reads them from there over the host link; the runtime's copy (API + DMA + 22-37 us until the dependent kernel starts,
     // profiles/r03_mono_single_trace_final.txt) drops out.  The block was last read by the previous frame's pyramid, which that call waited
     // for.  DVO_MONO_STAGE=0: the copy on the side stream, as before.
-    const bool stage_rows = stage_mono_rows;
     FrameInput fin;
     fin.rows_decimated = decimate_host_rows && can_decimate_rows(geoM);   // only the rows the pyramid keeps are copied / cross PCIe
     const size_t row_bytes = raw ? (size_t)w * raw_channels : (size_t)w * sizeof(float);
+    // (a thread's memcpy beats the runtime's copy path up to about half a megabyte -- measured at 77-460 KB; above that the DMA engine wins)
+    const bool stage_rows = stage_mono_rows && row_bytes * (size_t)(fin.rows_decimated ? h >> geoM.culls : h) <= kStageLimitBytes;
     if (stage_rows) {
         if (!h_stage) {
             DVO_TRY(alloc_stage());
@@ -1168,7 +1171,7 @@ int VisualOdometry::odometrize_depth_raw(const uint8_t* rgb, int channels, const
     if (side_built) { DVO_HIP(hipStreamWaitEvent(stream, uevent[1], 0)); side_built = false; }   // a float-map frame's depth pyramid may still be building: it is this call's reference
     // The kept rows of both frames (0.46 MB of 0.92 at cull 1) are staged by the caller's thread in pinned, device-mapped memory and read
     // from there by k_pyramid_raw4 -- no runtime copy (as in the mono loop; DVO_RAW_STAGE=0: two copies, the depth on the side stream).
-    if (stage_raw_rows) {
+    if (stage_raw_rows && ((size_t)w * channels + (size_t)w * 2) * (size_t)(in.rows_decimated ? h >> geoD.culls : h) <= kStageLimitBytes) {
         DVO_TRY(alloc_stage());
         char* hs = static_cast<char*>(h_stage);
         stage_rows_host(hs, rgb, (size_t)w * channels, h, geoD.culls, in.rows_decimated);
