@@ -808,6 +808,27 @@ def test_host_frame_staging_paths_give_the_same_bits(monkeypatch):
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def _holey(g, d, s):
+    """Frames whose border band and interior hold what the generic sampler exists for: INVALID gray blocks, black (0.0) pixels next to
+    them (the fill quirk of getSubpixel: `last > 0` is false), depth holes -- along all four image borders and inside."""
+    rng = np.random.RandomState(11)
+    out = []
+    for i in range(4):
+        gg, dd = g[i].copy(), d[i].copy()
+        for _ in range(60):
+            y, x = rng.randint(0, 470), rng.randint(0, 630)
+            gg[y:y + rng.randint(1, 9), x:x + rng.randint(1, 9)] = INV
+        for _ in range(40):
+            y, x = rng.randint(0, 478), rng.randint(0, 638)
+            gg[y:y + 2, x:x + 2] = 0.0
+        gg[0:3, ::7] = INV; gg[-3:, ::5] = 0.0; gg[::9, 0:3] = INV; gg[::11, -3:] = 0.0
+        for _ in range(30):
+            y, x = rng.randint(0, 470), rng.randint(0, 630)
+            dd[y:y + rng.randint(1, 9), x:x + rng.randint(1, 9)] = 0.0
+        out.append((gg, dd, s[i]))
+    return out
+
+
 def test_single_handle_one_launch_schedule_edge_cases():
     """k_track_persist (one launch per odometrizeUsingDepth call) where its control flow is unusual: a fixed iteration count (the
     level never 'stops' by a threshold), a reference without any usable depth (every step has zero contributing pixels: residual -1,
@@ -818,6 +839,7 @@ def test_single_handle_one_launch_schedule_edge_cases():
         "fixed_iterations": (dict(fixed_iterations=3, crop_enable=0), [(g[i], d[i], s[i]) for i in range(3)]),
         "no_depth": (dict(), [(g[0], np.zeros_like(d[0]), s[0]), (g[1], np.zeros_like(d[1]), s[1]), (g[2], d[2], s[2]), (g[3], d[3], s[3])]),
         "far_outside": (dict(), [(g[0], np.full_like(d[0], 1e-3 + 0.2), s[0]), (g[1], d[1], s[1]), (g[2], d[2], s[2])]),
+        "border_and_invalid_taps": (dict(), _holey(g, d, s)),
     }
     for name, (kw, seq) in cases.items():
         res = {}
