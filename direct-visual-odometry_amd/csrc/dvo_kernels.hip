@@ -426,11 +426,13 @@ __device__ __forceinline__ void gn_sample_fast(const Taps& t, float u, float v, 
 
 // The generic sampler (dvo_math.h gn_sample: any position, any validity pattern -- the fill quirk of getSubpixel, INVALID gradients at the
 // image border and next to INVALID taps, clamping of missing taps to g00) with every tap it can touch requested UP FRONT from clamped
-// coordinates: one memory round trip instead of the five or six dependent ones of the branchy version, whose branches skip most of the
-// work for most border pixels and therefore win where throughput counts (k_track_gn: measured, see gn_tile).  Where LATENCY counts -- one
-// sequence, k_track_persist: every step waits for its slowest tile, and the slowest tiles are those with border pixels (5.3-6.1 us against
-// 2.85 us for an interior tile, profiles/r03_single_cpp_final.txt) -- this form is used.  The same float operations on the same values:
-// bit-identical results (the schedules are compared bit for bit in tests/test_gpu_parity.py).
+// coordinates: one memory round trip instead of the five or six dependent ones of the branchy version, its semantics then evaluated from
+// registers with selects.  Written for k_track_persist, where every step waits for its slowest tile and the slowest tiles are those with
+// border pixels (5.3-6.1 us against 2.85 us for an interior tile: 6.1 -> 5.0 us, profiles/r03_single_cpp_final.txt); then measured in
+// the throughput kernels as well: +3.0 % frames/s on the 16 384-sequence batch (311.5 k -> 320.8 k, profiles/r03_patch_sampler_ab.txt) --
+// a round-1 attempt of the same idea had been 20 % slower on the probe and was the reason the branchy version stayed this long.
+// The same float operations on the same values: bit-identical results (tests/test_gpu_parity.py: operator-level masks against the
+// oracle, the schedules against each other, frames full of INVALID blocks, black pixels and depth holes).
 __device__ __forceinline__ bool gn_sample_patch(const float* __restrict__ img, const int w, const int h, const float d, const float u, const float v,
                                                 float& I2, float& gx, float& gy)
 {
@@ -495,14 +497,15 @@ struct GnTileLds {
 // consecutive raster pixels.  Used when the level width is a multiple of 64: only tiles on the image border then hold
 // deferred (border) pixels, a thread's pixels share their column (one int->float conversion and one (x - cx) for PPT
 // pixels) and there is no row-wrap arithmetic.
-// LAT: the deferred pixels take gn_sample_patch (one memory round trip) instead of the branchy generic sampler: for callers that wait for
-// the slowest tile of a single sequence (k_track_persist).
-template <int PPT, int G, bool MASK, bool T2D, bool LAT = false>
+template <int PPT, int G, bool MASK, bool T2D>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row);
 
 template <int PPT, int G, bool MASK, bool T2D = false>
-__global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(GnArgs a)  // 7 waves per SIMD = 72 VGPRs
+#if !defined(DVO_GN_WAVES)
+#define DVO_GN_WAVES 7   /* waves per SIMD the hot variants are compiled for: 7 = 72 VGPRs */
+#endif
+__global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? DVO_GN_WAVES : 1) k_track_gn(GnArgs a)
 {
     __shared__ GnTileLds<PPT> lds;
     // Workgroup 0 clears the counter of the list the following k_gn_solve appends to.  The store comes last on every path:
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? 7 : 1) k_track_gn(
     clear_next();
 }
 
-template <int PPT, int G, bool MASK, bool T2D, bool LAT>
+template <int PPT, int G, bool MASK, bool T2D>
 __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const int seq, const int blk, GnTileLds<PPT>& lds,
                                         float* out_row)
 {
@@ -689,8 +692,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
             // clamped coordinates -- one round trip, no divergent loads.  Slower by 20 % on the probe: the branches of the
             // memory version skip most of the work for most border pixels.)
             SlowSample ss;
-            if constexpr (LAT) ss.ok = gn_sample_patch(refp, w, h, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
-            else ss.ok = gn_sample(GlobalImg{refp, w, h}, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
+            ss.ok = gn_sample_patch(refp, w, h, d, u, v, ss.I2, ss.gx, ss.gy) ? 1 : 0;
             const bool ok = ss.ok != 0;
             float J[6], r, rw;
             gn_jacobian_pre(a.k, x, y, d, iz, wg, ss.gx, ss.gy, I1, ss.I2, J, r, rw);
@@ -1203,10 +1205,10 @@ __global__ void __launch_bounds__(256) k_track_persist(PersistArgs p)   // expon
             for (int t = me; t < L.blk_count; t += n_work) {
                 float* row = p.partials + (size_t)(L.blk_first + t) * 32;
                 if constexpr (PPT == 4) {
-                    if (L.t2d) gn_tile<PPT, G, false, true, true>(a, pose, 0, L.blk_first + t, lds, row);
-                    else gn_tile<PPT, G, false, false, true>(a, pose, 0, L.blk_first + t, lds, row);
+                    if (L.t2d) gn_tile<PPT, G, false, true>(a, pose, 0, L.blk_first + t, lds, row);
+                    else gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
                 } else {
-                    gn_tile<PPT, G, false, false, true>(a, pose, 0, L.blk_first + t, lds, row);
+                    gn_tile<PPT, G, false, false>(a, pose, 0, L.blk_first + t, lds, row);
                 }
                 __syncthreads();   // (the next tile reuses the LDS scratch)
             }
