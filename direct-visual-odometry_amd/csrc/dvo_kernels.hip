@@ -503,7 +503,7 @@ __device__ __forceinline__ void gn_tile(const GnArgs& a, const Pose& pose, const
 
 template <int PPT, int G, bool MASK, bool T2D = false>
 #if !defined(DVO_GN_WAVES)
-#define DVO_GN_WAVES 7   /* waves per SIMD the hot variants are compiled for: 7 = 72 VGPRs */
+#define DVO_GN_WAVES 6   /* waves per SIMD the hot variants are compiled for: 6 = up to 84 VGPRs (78 used, no scratch); at 7 (72 VGPRs) the border sampler spills 24 bytes per lane: 54 MB of extra HBM writes per full-batch launch for the same speed (profiles/r03_patch_sampler_ab.txt) */
 #endif
 __global__ void __launch_bounds__(256, (PPT <= 4 && G <= 2) ? DVO_GN_WAVES : 1) k_track_gn(GnArgs a)
 {
