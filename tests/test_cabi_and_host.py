@@ -101,8 +101,9 @@ def test_cpp_facade_header_compiles():
 
 
 def test_hot_kernel_fits_its_register_budget():
-    """k_track_gn is built for 7 waves per SIMD (72 VGPRs) and its time is proportional to its instruction count: one
-    spilled register costs tens of percent (measured).  The default variants must compile without scratch memory."""
+    """k_track_gn is built for 6 waves per SIMD (up to 84 VGPRs; 7 waves = 72 until the one-round-trip border sampler, which spilled
+    24 bytes there) and its time is proportional to its instruction count and its memory traffic: a spilled register is both.  The
+    default variants must compile without scratch memory."""
     import shutil
     import subprocess
     import tempfile
@@ -130,7 +131,7 @@ def test_hot_kernel_fits_its_register_budget():
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert scratch == 0, "%s spills %d bytes of scratch per lane" % (variant, scratch)
-        assert vgpr <= 72, "%s needs %d VGPRs (budget 72 = 7 waves per SIMD)" % (variant, vgpr)
+        assert vgpr <= 84, "%s needs %d VGPRs (budget 84 = 6 waves per SIMD)" % (variant, vgpr)
         checked += 1
     assert checked == 2
 
